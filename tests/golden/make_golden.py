@@ -1,0 +1,387 @@
+#!/usr/bin/env python3
+"""
+Golden-vector generator.  TEST INFRASTRUCTURE, runs only in the build container.
+
+Imports the *reference* XICSRT (read-only at /root/reference, v0.8.13, pure
+NumPy) and records, for a list of small configurations, what the reference
+produces on a fixed seed:
+
+  kind 'trace'  : one iteration through the reference's own
+                  xicsrt_raytrace._raytrace_iter (xicsrt_raytrace.py:178) with
+                  keep_history=True -> the full per-element ray arrays in
+                  original ray order (origin, direction, wavelength, mask),
+                  per-element num_out, per-optic images and the next double
+                  of the global np.random stream after the iteration (stream
+                  accounting check).
+  kind 'counts' : xicsrt.raytrace(config) (xicsrt_raytrace.py:28) with
+                  keep_history=False -> summed num_out and images over
+                  runs x iterations.
+
+Nothing from the reference is copied: fixtures hold inputs (config as JSON) and
+outputs (arrays) only.  The reference never travels to the GPU box; these .npz
+files do.
+
+Usage (from anywhere):
+    PYTHONDONTWRITEBYTECODE=1 python3 tests/golden/make_golden.py [case ...]
+"""
+import sys
+import os
+import json
+import copy
+import hashlib
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REFERENCE = '/root/reference'
+
+# The reference must win over any same-named package on the path.
+sys.path = [REFERENCE] + [p for p in sys.path
+                          if os.path.abspath(p or '.') not in
+                          (os.path.dirname(os.path.dirname(HERE)),)]
+sys.dont_write_bytecode = True
+
+import numpy as np  # noqa: E402
+import logging  # noqa: E402
+logging.disable(logging.WARNING)
+
+import xicsrt  # noqa: E402
+assert os.path.abspath(xicsrt.__file__).startswith(REFERENCE), xicsrt.__file__
+from xicsrt import xicsrt_raytrace, xicsrt_config  # noqa: E402
+from xicsrt.objects._Dispatcher import Dispatcher  # noqa: E402
+
+
+# ---------------------------------------------------------------------------
+# configurations (geometry of examples/example_00, example_01 cell 2 and
+# testing/integrated_test_01 cell 2)
+# ---------------------------------------------------------------------------
+
+def _general(seed=0, runs=1, iters=1, history=False):
+    return {
+        'number_of_iter': iters,
+        'number_of_runs': runs,
+        'random_seed': seed,
+        'keep_history': history,
+        'keep_images': True,
+        'print_results': False,
+        'strict_config_check': True,
+    }
+
+
+def _source(n, spread_deg=10.0, **kw):
+    s = {
+        'class_name': 'XicsrtSourceDirected',
+        'intensity': n,
+        'wavelength': 3.9492,
+        'spread': float(np.radians(spread_deg)),
+        'xsize': 0.0, 'ysize': 0.0, 'zsize': 0.0,
+    }
+    s.update(kw)
+    return s
+
+
+def _crystal(class_name, **kw):
+    c = {
+        'class_name': class_name,
+        'check_size': True,
+        'origin': [0.0, 0.0, 0.80374151],
+        'zaxis': [0.0, 0.59497864, -0.80374151],
+        'xsize': 0.2,
+        'ysize': 0.2,
+    }
+    c.update(kw)
+    return c
+
+
+_BRAGG = {'crystal_spacing': 2.45676, 'rocking_type': 'gaussian',
+          'rocking_fwhm': 48.070e-6}
+
+
+def _detector(**kw):
+    d = {
+        'class_name': 'XicsrtOpticDetector',
+        'origin': [0.0, 0.76871290, 0.56904832],
+        'zaxis': [0.0, -0.95641806, 0.29200084],
+        'xsize': 0.4,
+        'ysize': 0.2,
+    }
+    d.update(kw)
+    return d
+
+
+def cfg_example00(n, seed=0, **g):
+    return {
+        'general': _general(seed, **g),
+        'sources': {'source': _source(n, 5.0)},
+        'optics': {'detector': {
+            'class_name': 'XicsrtOpticDetector',
+            'origin': [0.0, 0.0, 1.0], 'zaxis': [0.0, 0.0, -1.0],
+            'xsize': 0.2, 'ysize': 0.2}},
+    }
+
+
+def cfg_three(n, crystal, seed=0, source=None, detector=None, **g):
+    return {
+        'general': _general(seed, **g),
+        'sources': {'source': source if source is not None else _source(n)},
+        'optics': {'crystal': crystal,
+                   'detector': detector if detector is not None else _detector()},
+    }
+
+
+def build_cases():
+    C = {}
+
+    def add(name, kind, cfg):
+        C[name] = (kind, cfg)
+
+    sph = _crystal('XicsrtOpticSphericalCrystal', radius=1.0, **_BRAGG)
+    mir = _crystal('XicsrtOpticPlanarMirror')
+
+    # --- BASELINE cfg1: example_00 ---------------------------------------
+    add('A_example00_trace', 'trace', cfg_example00(500, history=True))
+    add('A_example00_1e5', 'counts', cfg_example00(100000))
+    # --- BASELINE cfg2: planar mirror --------------------------------------
+    add('B_mirror_trace', 'trace', cfg_three(500, mir, history=True))
+    add('B_mirror_1e5', 'counts', cfg_three(100000, mir))
+    add('B_mirror_runs', 'counts', cfg_three(20000, mir, seed=2, runs=3))
+    # --- BASELINE cfg3: spherical Bragg crystal --------------------------
+    add('C_sphere_trace', 'trace', cfg_three(2000, sph, history=True))
+    add('C_sphere_1e5', 'counts', cfg_three(100000, sph))
+    add('C_sphere_2e5_s3', 'counts', cfg_three(200000, sph, seed=3))
+    add('C_sphere_runs', 'counts', cfg_three(10000, sph, seed=5, runs=4))
+    add('C_sphere_iters', 'counts', cfg_three(10000, sph, seed=7, iters=3))
+    add('C_sphere_runs_iters', 'counts',
+        cfg_three(5000, sph, seed=11, runs=3, iters=2))
+    c = dict(sph, check_bragg=False)
+    add('C_sphere_nobragg_trace', 'trace', cfg_three(500, c, history=True))
+    add('C_sphere_nobragg_1e5', 'counts', cfg_three(100000, c))
+    c = dict(sph, rocking_type='step', rocking_fwhm=2.0e-3)
+    add('C_sphere_step_trace', 'trace', cfg_three(2000, c, history=True))
+    add('C_sphere_step_1e5', 'counts', cfg_three(100000, c))
+    c = dict(sph, reflectivity=0.5, rocking_fwhm=1.0e-3)
+    add('C_sphere_refl_1e5', 'counts', cfg_three(100000, c))
+    c = dict(sph, convex=True, check_bragg=False)
+    add('C_sphere_convex_trace', 'trace', cfg_three(500, c, history=True))
+    # --- other analytic optic classes (integrated_test_01 sweep) ---------
+    for cls, extra in [
+            ('XicsrtOpticSphericalMirror', {'radius': 1.0}),
+            ('XicsrtOpticPlanarCrystal', dict(_BRAGG, check_bragg=False)),
+            ('XicsrtOpticPlanarCrystal', dict(_BRAGG, rocking_fwhm=5e-2)),
+            ('XicsrtOpticCylindricalCrystal', dict(_BRAGG, radius=1.0, check_bragg=False)),
+            ('XicsrtOpticCylindricalMirror', {'radius': 1.0, 'convex': True}),
+            ('XicsrtOpticToroidalCrystal', dict(_BRAGG, radius_major=1.0, radius_minor=0.2,
+                                                check_bragg=False)),
+            ]:
+        tag = cls.replace('XicsrtOptic', '')
+        if 'rocking_fwhm' in extra and extra['rocking_fwhm'] == 5e-2:
+            tag += '_bragg'
+        if extra.get('convex'):
+            tag += '_convex'
+        c = _crystal(cls, **extra)
+        add('D_%s_trace' % tag, 'trace', cfg_three(500, c, history=True))
+        add('D_%s_1e5' % tag, 'counts', cfg_three(100000, c))
+
+    # --- sources: extended, tilted, generic, focused ---------------------
+    wide = dict(sph, rocking_fwhm=5.0e-3)
+    tilt = {'origin': [0.01, -0.02, 0.03],
+            'zaxis': [0.0, 0.6, 0.8], 'xaxis': [1.0, 0.0, 0.0]}
+    s = _source(500, 10.0, xsize=0.01, ysize=0.02, zsize=0.005)
+    add('S_extended_trace', 'trace', cfg_three(500, wide, source=s, history=True, seed=7))
+    s = dict(_source(500, 12.0, xsize=0.01, ysize=0.02, zsize=0.005), **tilt)
+    s['direction'] = [0.05, -0.05, 1.0]
+    add('S_tilted_directed_trace', 'trace', cfg_three(500, dict(sph, check_bragg=False), source=s, history=True, seed=8))
+    s = dict(_source(500, 12.0, xsize=0.01, ysize=0.02, zsize=0.005),
+             class_name='XicsrtSourceGeneric')
+    add('S_generic_trace', 'trace', cfg_three(500, wide, source=s, history=True, seed=9))
+    s = dict(_source(500, 2.0, xsize=0.05, ysize=0.05, zsize=0.05),
+             class_name='XicsrtSourceFocused', target=[0.0, 0.0, 0.80374151])
+    add('S_focused_trace', 'trace', cfg_three(500, wide, source=s, history=True, seed=10))
+    s = dict(s, intensity=100000)
+    add('S_focused_1e5', 'counts', cfg_three(100000, wide, source=s, seed=10))
+    s = dict(_source(500, 10.0, xsize=0.01, ysize=0.02, zsize=0.005),
+             spatial_dist='gaussian')
+    add('S_gaussian_spatial_trace', 'trace', cfg_three(500, wide, source=s, history=True, seed=12))
+
+    # --- wavelength distributions ------------------------------------------
+    s = _source(2000, 10.0, wavelength_dist='uniform', wavelength_range=[3.9480, 3.9500])
+    add('W_uniform_trace', 'trace', cfg_three(2000, sph, source=s, history=True, seed=21))
+    s = dict(s, intensity=100000)
+    add('W_uniform_1e5', 'counts', cfg_three(100000, sph, source=s, seed=21))
+    s = _source(2000, 10.0, wavelength_dist='monochrome')
+    add('W_monochrome_trace', 'trace', cfg_three(2000, sph, source=s, history=True, seed=22))
+    s = _source(2000, 10.0, linewidth=1.129e14, temperature=1000.0, mass_number=39.948)
+    add('W_voigt_trace', 'trace', cfg_three(2000, sph, source=s, history=True, seed=23))
+    s = dict(s, intensity=100000)
+    add('W_voigt_1e5', 'counts', cfg_three(100000, sph, source=s, seed=23))
+    s = _source(2000, 10.0, temperature=1000.0, mass_number=39.948)
+    add('W_normal_trace', 'trace', cfg_three(2000, sph, source=s, history=True, seed=24))
+    s = dict(s, intensity=100000)
+    add('W_normal_1e5', 'counts', cfg_three(100000, sph, source=s, seed=24))
+    s = _source(2000, 10.0, temperature=1000.0, mass_number=39.948,
+                velocity=[1.0e4, -2.0e4, 3.0e4])
+    add('W_doppler_trace', 'trace', cfg_three(2000, sph, source=s, history=True, seed=25))
+
+    # --- angular distributions ---------------------------------------------
+    for dist, spread in [('isotropic_xy', [0.10, 0.05]), ('flat', 0.17),
+                         ('flat_xy', [-0.1, 0.15, -0.05, 0.08])]:
+        s = _source(500, 10.0, angular_dist=dist)
+        s['spread'] = spread
+        add('G_%s_trace' % dist, 'trace', cfg_three(500, mir, source=s, history=True, seed=31))
+        s = dict(s, intensity=50000)
+        add('G_%s_5e4' % dist, 'counts', cfg_three(50000, mir, source=s, seed=31))
+
+    # --- apertures / bounds / local tracing --------------------------------
+    ap = [{'shape': 'circle', 'size': [0.08]},
+          {'shape': 'rectangle', 'size': [0.05, 0.02], 'origin': [0.01, 0.0], 'logic': 'not'}]
+    c = dict(mir, aperture=ap)
+    add('P_aperture_trace', 'trace', cfg_three(2000, c, history=True, seed=41))
+    add('P_aperture_1e5', 'counts', cfg_three(100000, c, seed=41))
+    ap = [{'shape': 'ellipse', 'size': [0.09, 0.05]},
+          {'shape': 'square', 'size': [0.03], 'origin': [0.02, 0.01], 'logic': 'xor'},
+          {'shape': 'triangle', 'vertices': [[-0.05, -0.05], [0.05, -0.05], [0.0, 0.06]],
+           'logic': 'or'}]
+    c = dict(mir, aperture=ap)
+    add('P_aperture2_trace', 'trace', cfg_three(2000, c, history=True, seed=42))
+    c = dict(mir, check_size=False)
+    add('P_nosize_trace', 'trace', cfg_three(500, c, history=True, seed=43))
+    c = dict(mir, trace_local=True)
+    add('P_local_trace', 'trace', cfg_three(500, c, history=True, seed=44))
+    c = dict(sph, zsize=0.004)
+    add('P_zsize_trace', 'trace', cfg_three(500, c, history=True, seed=45))
+    d = _detector(pixel_size=0.0005)
+    add('P_pixels_1e5', 'counts', cfg_three(100000, sph, detector=d, seed=46))
+
+    # --- four elements: two crystals in sequence (two ranked RNG draws) ----
+    cfg = cfg_three(2000, dict(sph, rocking_fwhm=2e-3), history=True, seed=51)
+    cfg['optics'] = {
+        'aperture': {'class_name': 'XicsrtOpticAperture', 'origin': [0.0, 0.0, 0.4],
+                     'zaxis': [0.0, 0.0, -1.0], 'xsize': 0.12, 'ysize': 0.12,
+                     'aperture': [{'shape': 'circle', 'size': [0.055]}]},
+        'crystal': cfg['optics']['crystal'],
+        'crystal2': _crystal('XicsrtOpticPlanarCrystal',
+                             origin=[0.0, 0.3826, 0.6869], zaxis=[0.0, -0.9426, -0.3342],
+                             xsize=0.4, ysize=0.4, reflectivity=0.7,
+                             **dict(_BRAGG, rocking_fwhm=0.2)),
+        'detector': _detector(origin=[0.0, 0.2149, 0.4381], zaxis=[0.0, 0.5591, 0.8293],
+                              xsize=0.4, ysize=0.4),
+    }
+    add('Q_four_trace', 'trace', cfg)
+    cfg2 = copy.deepcopy(cfg)
+    cfg2['general'].update(keep_history=False, number_of_iter=2, number_of_runs=2)
+    cfg2['sources']['source']['intensity'] = 50000
+    add('Q_four_counts', 'counts', cfg2)
+
+    # --- plasma cube (BASELINE cfg4 shape, small) ---------------------------
+    p = {'class_name': 'XicsrtPlasmaCubic', 'origin': [0.0, 0.0, 0.0],
+         'xsize': 0.1, 'ysize': 0.1, 'zsize': 0.1,
+         'target': [0.0, 0.0, 0.80374151], 'emissivity': 2e15 / 50, 'time_resolution': 1e-3,
+         'temperature': 1000.0, 'mass_number': 39.948, 'linewidth': 0.0,
+         'wavelength': 3.9492, 'spread': float(np.radians(1.0)), 'use_poisson': True,
+         'bundle_count': 200, 'bundle_volume': 0.001 / 200, 'bundle_type': 'voxel'}
+    add('F_plasma_trace', 'trace', cfg_three(0, sph, source=p, history=True, seed=61))
+    add('F_plasma_counts', 'counts', cfg_three(0, sph, source=dict(p, emissivity=2e15 / 5),
+                                               seed=61, runs=2))
+    # --- mesh optics (BASELINE cfg5 shape, small) ---------------------------
+    for interp in (False, True):
+        c = _crystal('XicsrtOpticMeshToroidalCrystal', radius_major=1.0, radius_minor=0.2,
+                     mesh_size=[41, 41], mesh_interpolate=interp,
+                     **dict(_BRAGG, check_bragg=False))
+        tag = 'interp' if interp else 'flat'
+        add('E_mesh_%s_trace' % tag, 'trace', cfg_three(500, c, history=True, seed=71))
+    return C
+
+
+# ---------------------------------------------------------------------------
+
+def _jsonable(obj):
+    if isinstance(obj, dict):
+        return {k: _jsonable(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return [_jsonable(v) for v in obj]
+    if isinstance(obj, np.ndarray):
+        return obj.tolist()
+    if isinstance(obj, (np.floating,)):
+        return float(obj)
+    if isinstance(obj, (np.integer,)):
+        return int(obj)
+    if isinstance(obj, (np.bool_,)):
+        return bool(obj)
+    return obj
+
+
+def run_trace(cfg):
+    """One iteration via the reference's internals, rays kept in original order."""
+    cfg = copy.deepcopy(cfg)
+    config = xicsrt_config.config_to_numpy(cfg)
+    config = xicsrt_config.get_config(config)
+    np.random.seed(config['general']['random_seed'])
+    filters = Dispatcher(config, 'filters')
+    filters.instantiate(); filters.setup(); filters.initialize()
+    sources = Dispatcher(config, 'sources')
+    sources.instantiate(); sources.apply_filters(filters)
+    sources.setup(); sources.check_param(); sources.initialize()
+    optics = Dispatcher(config, 'optics')
+    optics.instantiate(); optics.apply_filters(filters)
+    optics.setup(); optics.check_param(); optics.initialize()
+    single = xicsrt_raytrace._raytrace_iter(config, sources, optics)
+    out = {}
+    names = list(single['meta'].keys())
+    out['names'] = np.array(names)
+    for k in names:
+        out['num_out/' + k] = np.int64(single['meta'][k]['num_out'])
+        h = single['history'][k]
+        out['origin/' + k] = np.asarray(h['origin'], dtype=np.float64)
+        out['direction/' + k] = np.asarray(h['direction'], dtype=np.float64)
+        out['wavelength/' + k] = np.asarray(h['wavelength'], dtype=np.float64)
+        out['mask/' + k] = np.asarray(h['mask'], dtype=np.bool_)
+        img = single['image'].get(k)
+        if img is not None:
+            assert np.array_equal(img, np.round(img))
+            out['image/' + k] = img.astype(np.int64)
+    out['next_double'] = np.float64(np.random.random_sample())
+    return out
+
+
+def run_counts(cfg):
+    cfg = copy.deepcopy(cfg)
+    res = xicsrt.raytrace(cfg)
+    out = {}
+    names = list(res['total']['meta'].keys())
+    out['names'] = np.array(names)
+    for k in names:
+        out['num_out/' + k] = np.int64(res['total']['meta'][k]['num_out'])
+        img = res['total']['image'].get(k)
+        if img is not None:
+            assert np.array_equal(img, np.round(img))
+            out['image/' + k] = img.astype(np.int64)
+    return out
+
+
+def main(argv):
+    cases = build_cases()
+    want = argv[1:] or list(cases)
+    index = {}
+    index_path = os.path.join(HERE, 'INDEX.json')
+    if os.path.exists(index_path):
+        index = json.load(open(index_path))
+    for name in want:
+        kind, cfg = cases[name]
+        try:
+            out = run_trace(cfg) if kind == 'trace' else run_counts(cfg)
+        except Exception as e:  # reference raised: record that, it is part of the contract
+            print('%-32s REFERENCE RAISED %s: %s' % (name, type(e).__name__, e))
+            continue
+        out['config_json'] = np.array(json.dumps(_jsonable(cfg)))
+        out['kind'] = np.array(kind)
+        path = os.path.join(HERE, name + '.npz')
+        np.savez_compressed(path, **out)
+        counts = {k[8:]: int(v) for k, v in out.items() if k.startswith('num_out/')}
+        hashes = {k[6:]: hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest()[:16]
+                  for k, v in out.items() if k.startswith('image/')}
+        index[name] = {'kind': kind, 'num_out': counts, 'image_sha256_16': hashes,
+                       'bytes': os.path.getsize(path)}
+        print('%-32s %s' % (name, counts))
+    json.dump(index, open(index_path, 'w'), indent=1, sort_keys=True)
+
+
+if __name__ == '__main__':
+    main(sys.argv)
