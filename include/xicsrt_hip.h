@@ -1,0 +1,242 @@
+/*
+ * xicsrt_hip.h -- C ABI of the MI355X-native photon propagation path.
+ *
+ * Boundary: this is what the host side (Python, ctypes) binds in place of the
+ * reference's NumPy hot path.  Everything crossing it is plain C: fixed-layout
+ * structs, pointers and sizes.  No torch / numpy / C++ types.
+ *
+ *   reference interface replaced                      entry point here
+ *   ------------------------------------------------  ---------------------------
+ *   xicsrt_raytrace.raytrace          (xicsrt/xicsrt_raytrace.py:28)   xrt_trace (run loop, seeds per run)
+ *   xicsrt_raytrace.raytrace_single   (xicsrt/xicsrt_raytrace.py:87)   xrt_trace (np.random.seed :111, iteration loop :153)
+ *   xicsrt_raytrace._raytrace_iter    (xicsrt/xicsrt_raytrace.py:178)  xrt_trace / xrt_trace_history
+ *   Dispatcher.generate_rays          (xicsrt/objects/_Dispatcher.py:142)   source stage of the kernel
+ *   Dispatcher.trace                  (xicsrt/objects/_Dispatcher.py:166)   optic stages, num_out, images
+ *   TraceObject.make_image            (xicsrt/optics/_TraceObject.py:234)   images[] accumulation
+ *   history deepcopy per element      (xicsrt/objects/_Dispatcher.py:162,187)  xrt_trace_history
+ *   combine_raytrace (sum of meta/images over runs and iterations,
+ *                     xicsrt/xicsrt_raytrace.py:328-356)   accumulation into num_out[] / images[]
+ *
+ * The scene structs below are the flattened `param` dictionaries of the
+ * reference's initialised objects (ConfigObject.param, objects/_ConfigObject.py:33):
+ * all scalar set-up arithmetic (cos(spread), xsize/2, 2*d, 2*sigma^2, sphere
+ * centre ...) is done by the host exactly as the reference's setup()/initialize()
+ * do it, and handed over as doubles.
+ *
+ * Conventions: return value 0 = ok, negative = error (text via xrt_last_error()).
+ * The library never throws across the ABI, never allocates on behalf of the
+ * caller and never synchronises the device: the caller owns every buffer (device
+ * pointers are ordinary HIP device addresses, e.g. torch tensors' data_ptr()),
+ * passes the HIP stream to launch on, and synchronises that stream itself.
+ * A handle-free design: every call is self-contained; calls on different
+ * streams/devices may be made from different threads.
+ */
+#ifndef XICSRT_HIP_H
+#define XICSRT_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XRT_ABI_VERSION 3
+
+#define XRT_MAX_OPTICS     16
+#define XRT_MAX_APERTURES  8
+
+/* ---- enumerations -------------------------------------------------------- */
+
+/* cone-axis rule of the source (sources/_XicsrtSourceGeneric.py:262,
+ * _XicsrtSourceDirected.py:46, _XicsrtSourceFocused.py:40) */
+enum { XRT_SRC_GENERIC = 0, XRT_SRC_DIRECTED = 1, XRT_SRC_FOCUSED = 2 };
+/* spatial_dist (_XicsrtSourceGeneric.py:231,237) */
+enum { XRT_SPATIAL_UNIFORM = 0, XRT_SPATIAL_GAUSSIAN = 1 };
+/* angular_dist (tools/xicsrt_spread.py:21) */
+enum { XRT_ANG_ISOTROPIC = 0, XRT_ANG_ISOTROPIC_XY = 1, XRT_ANG_FLAT = 2, XRT_ANG_FLAT_XY = 3 };
+/* effective wavelength sampler after the reference's own case analysis
+ * (_XicsrtSourceGeneric.py:295-367): CONST consumes no random numbers. */
+enum { XRT_WL_CONST = 0, XRT_WL_UNIFORM = 1, XRT_WL_NORMAL = 2, XRT_WL_VOIGT = 3 };
+
+/* Shape* classes (optics/_ShapePlane.py, _ShapeSphere.py, _ShapeCylinder.py, _ShapeTorus.py) */
+enum { XRT_SHAPE_PLANE = 0, XRT_SHAPE_SPHERE = 1, XRT_SHAPE_CYLINDER = 2, XRT_SHAPE_TORUS = 3 };
+/* Interact* classes (optics/_InteractNone.py, _InteractMirror.py, _InteractCrystal.py) */
+enum { XRT_INTERACT_NONE = 0, XRT_INTERACT_MIRROR = 1, XRT_INTERACT_CRYSTAL = 2 };
+/* rocking_type (optics/_InteractCrystal.py:138-149) */
+enum { XRT_ROCKING_STEP = 0, XRT_ROCKING_GAUSS = 1 };
+
+/* aperture shapes and logic (tools/xicsrt_aperture.py:13-204) */
+enum { XRT_AP_NONE = 0, XRT_AP_CIRCLE = 1, XRT_AP_SQUARE = 2, XRT_AP_RECTANGLE = 3,
+       XRT_AP_ELLIPSE = 4, XRT_AP_TRIANGLE = 5 };
+enum { XRT_LOGIC_AND = 0, XRT_LOGIC_NOT = 1, XRT_LOGIC_OR = 2, XRT_LOGIC_NAND = 3,
+       XRT_LOGIC_NOR = 4, XRT_LOGIC_XOR = 5, XRT_LOGIC_XNOR = 6 };
+
+/* optic flags */
+enum {
+    XRT_F_CHECK_SIZE     = 1 << 0,   /* param['check_size']      (_TraceObject.py:204) */
+    XRT_F_CHECK_APERTURE = 1 << 1,   /* param['check_aperture']  (_TraceObject.py:227) */
+    XRT_F_HAS_XSIZE      = 1 << 2,   /* xsize is not None        (_TraceObject.py:205) */
+    XRT_F_HAS_YSIZE      = 1 << 3,
+    XRT_F_HAS_ZSIZE      = 1 << 4,
+    XRT_F_CONVEX         = 1 << 5,   /* param['convex']          (_ShapeSphere.py:95)  */
+    XRT_F_CHECK_BRAGG    = 1 << 6,   /* param['check_bragg']     (_InteractCrystal.py:120) */
+    XRT_F_IMAGE          = 1 << 7,   /* param['enable_image']    (_TraceObject.py:131) */
+    XRT_F_TRACE_LOCAL    = 1 << 8    /* param['trace_local']     (_TraceObject.py:146) */
+};
+
+/* ---- scene --------------------------------------------------------------- */
+
+typedef struct xrt_aperture {
+    int32_t shape;
+    int32_t logic;
+    double  origin[2];
+    double  size[2];          /* circle: size[0]=radius; square: size[0]; rectangle/ellipse: x,y */
+    double  vertices[6];      /* triangle: x0,y0,x1,y1,x2,y2 with the aperture origin already added */
+} xrt_aperture_t;
+
+typedef struct xrt_source {
+    int32_t kind;             /* XRT_SRC_*      */
+    int32_t spatial_dist;     /* XRT_SPATIAL_*  */
+    int32_t angular_dist;     /* XRT_ANG_*      */
+    int32_t wavelength_dist;  /* XRT_WL_*       */
+    int64_t intensity;        /* rays per iteration, param['intensity'] after initialize() */
+    double  origin[3];        /* GeometryObject.origin                                     */
+    double  orientation[9];   /* rows xaxis, yaxis = zaxis x xaxis, zaxis (_GeometryObject.py:94) */
+    double  size[3];          /* xsize, ysize, zsize (full widths)                         */
+    double  spatial_A[9];     /* GAUSSIAN: sqrt(s)[:,None]*v of svd(cov), row-major (np.random.multivariate_normal) */
+    double  axis[3];         /* GENERIC: param zaxis; DIRECTED: param direction; FOCUSED: target */
+    /* angular distribution constants, computed by the host as the reference does:
+     *   ISOTROPIC    ang[0] = cos(spread)            (xicsrt_spread.py:102)
+     *   FLAT         ang[0] = tan(spread)            (xicsrt_spread.py:235)
+     *   FLAT_XY      ang[0..3] = tan(theta[0..3])    (xicsrt_spread.py:282-284)
+     *   ISOTROPIC_XY ang[0] = cos(theta_max), ang[1..4] = sin(theta[0..3]) (xicsrt_spread.py:173-186) */
+    double  ang[5];
+    double  two_pi;           /* 2*np.pi as the host computes it                           */
+    double  wavelength;       /* CONST / NORMAL loc / VOIGT centre                         */
+    double  wl_a, wl_b;       /* UNIFORM: low, high-low; NORMAL: sigma in wl_a; VOIGT: cdf min, (cdf max - cdf min) */
+    int32_t has_velocity;     /* not np.all(velocity == 0) (_XicsrtSourceGeneric.py:314)   */
+    int32_t voigt_n;          /* number of table points                                    */
+    double  velocity[3];
+    double  light_speed;      /* scipy.constants c                                         */
+    const double* voigt_cdf;  /* HOST pointers, voigt_n doubles each; copied per call      */
+    const double* voigt_x;
+} xrt_source_t;
+
+typedef struct xrt_optic {
+    int32_t shape;            /* XRT_SHAPE_*    */
+    int32_t interact;         /* XRT_INTERACT_* */
+    int32_t flags;            /* XRT_F_*        */
+    int32_t rocking_type;     /* XRT_ROCKING_*  */
+    double  origin[3];
+    double  orientation[9];
+    double  half_size[3];     /* xsize/2, ysize/2, zsize/2                                 */
+    double  radius;           /* sphere / cylinder                                         */
+    double  radius2;          /* radius**2 as the host computes it                         */
+    double  center[3];        /* sphere / cylinder / torus centre (_ShapeSphere.py:43)     */
+    double  torus_major;      /* torus frame major radius (_ShapeTorus.py:72-91)           */
+    double  torus_minor;
+    int32_t torus_root;       /* quartic root column                                       */
+    int32_t n_apertures;
+    double  two_d;            /* 2*crystal_spacing            (_InteractCrystal.py:110)    */
+    double  reflectivity;
+    double  rocking_half_fwhm;/* STEP: rocking_fwhm/2         (_InteractCrystal.py:141)    */
+    double  rocking_2sigma2;  /* GAUSS: 2*sigma**2            (_InteractCrystal.py:146-149)*/
+    double  half_pi;          /* np.pi/2                      (_InteractCrystal.py:112)    */
+    double  pixel_size;       /* (_TraceObject.py:107)                                     */
+    double  pixel_xoff;       /* (pixel_xsize-1)/2            (_TraceObject.py:269)        */
+    double  pixel_yoff;
+    int32_t pixel_nx;
+    int32_t pixel_ny;
+    int64_t image_offset;     /* first bin of this optic's image in images[] (row-major [nx][ny]) */
+    xrt_aperture_t apertures[XRT_MAX_APERTURES];
+} xrt_optic_t;
+
+typedef struct xrt_scene {
+    xrt_source_t source;
+    int32_t      n_optics;
+    int32_t      reserved;
+    int64_t      image_bins;  /* total number of bins of all images                        */
+    xrt_optic_t  optics[XRT_MAX_OPTICS];
+} xrt_scene_t;
+
+/* numpy legacy RandomState (MT19937 key + position + cached gaussian), the
+ * state np.random.get_state()/set_state() exchange. */
+typedef struct xrt_rng_state {
+    uint32_t key[624];
+    int32_t  pos;             /* 0..624; 624 = regenerate before the next word */
+    int32_t  has_gauss;
+    double   gauss;
+} xrt_rng_state_t;
+
+/* History snapshot of ONE run/iteration (Dispatcher history deepcopy,
+ * objects/_Dispatcher.py:162,187): for element e (0 = source, 1.. = optics) and
+ * original ray index i, structure-of-arrays
+ *     rays[(e*8 + c)*n_rays + i],  c = ox,oy,oz,dx,dy,dz,wavelength,weight
+ *     mask[e*n_rays + i]
+ * Only rays alive after element e are written; the caller pre-fills the rest
+ * (the reference leaves NaN origins there). */
+#define XRT_HIST_COMPONENTS 8
+
+/* ---- entry points -------------------------------------------------------- */
+
+int         xrt_abi_version(void);
+const char* xrt_last_error(void);
+
+/* Size of struct xrt_scene as compiled, so a binding can verify its layout. */
+size_t      xrt_sizeof_scene(void);
+
+/* Static validation of a scene (no device work): 0 if the device path implements it. */
+int         xrt_scene_check(const xrt_scene_t* scene);
+
+/* Number of HIP devices visible (hipGetDeviceCount). */
+int         xrt_device_count(int* count);
+
+/* Bytes of device scratch xrt_trace needs for this problem. */
+size_t      xrt_workspace_bytes(const xrt_scene_t* scene, int32_t n_runs);
+
+/*
+ * Trace n_runs independent runs (one MT19937 stream each, seeded
+ * init_genrand(seeds[r]) like np.random.seed, xicsrt_raytrace.py:111), each of
+ * n_iter iterations sharing the run's stream (xicsrt_raytrace.py:153), on the
+ * current device.  Adds into
+ *     num_out[0 .. n_optics]          device u64, rays alive after each element
+ *     images[0 .. scene->image_bins)  device u64, per-optic pixel counts
+ * (the caller zeroes them; repeated calls accumulate, which is the reference's
+ * combine_raytrace sum).  `images` may be NULL when keep_images is off.
+ * Asynchronous on `stream` (a hipStream_t; NULL = default stream).
+ */
+int xrt_trace(const xrt_scene_t* scene,
+              const uint32_t* seeds, int32_t n_runs, int32_t n_iter,
+              uint64_t* num_out, uint64_t* images,
+              void* workspace, size_t workspace_bytes,
+              void* stream);
+
+/*
+ * One iteration from an explicit generator state, keeping the per-element
+ * history (keep_history=True; also the single-object plug-in calls, which take
+ * the global np.random state in and hand the advanced state back): as
+ * xrt_trace with n_runs = n_iter = 1, and additionally fills the device buffers
+ * `rays` (double, (n_optics+1)*8*n_rays), `mask` (uint8, (n_optics+1)*n_rays)
+ * described above and `state_out` (one xrt_rng_state_t in device memory: the
+ * generator state after the iteration).  `state_in` is host memory.
+ * A ray that dies at element e is written at e with mask 0 and the point it
+ * died at (NaN origin if it had no intersection), direction unchanged.
+ */
+int xrt_trace_history(const xrt_scene_t* scene, const xrt_rng_state_t* state_in,
+                      uint64_t* num_out, uint64_t* images,
+                      double* rays, uint8_t* mask, void* state_out,
+                      void* workspace, size_t workspace_bytes,
+                      void* stream);
+
+/* Name and average duration (ms) bookkeeping of the propagation kernel for the
+ * benchmark: brackets the kernel launches of the next xrt_trace calls with HIP
+ * events on the launch stream.  xrt_timing_begin resets, xrt_timing_end
+ * synchronises the events and returns total kernel milliseconds and launches. */
+int xrt_timing_begin(void);
+int xrt_timing_end(double* kernel_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XICSRT_HIP_H */

@@ -1,0 +1,776 @@
+/*
+ * xrt_oracle.c -- CPU ORACLE.  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * A plain-C restatement of the reference's (PrincetonUniversity/xicsrt v0.8.13,
+ * pure NumPy) per-photon propagation path, written from the reference's
+ * behaviour, array-at-a-time in the reference's own call order so that the
+ * global np.random stream is consumed exactly as the reference consumes it.
+ * Every function cites the reference file:line it follows.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this.  The product (xicsrt_amd/) never does.
+ *
+ * PARITY PINNING: pinned against golden vectors generated in the build
+ * container by importing the reference itself (tests/golden/make_golden.py,
+ * numpy 2.2.6 / OpenBLAS as shipped there): integer results (num_out, images,
+ * masks) bit-exact; floating-point ray arrays to <= 1e-12 relative (the
+ * third-party libm/SVML transcendentals of NumPy differ from glibc in the last
+ * ulp).  Third-party arithmetic restated here (not in /root/reference):
+ *   - numpy legacy RandomState: MT19937 init_genrand seeding, genrand_res53
+ *     doubles, uniform = low + (high-low)*d, polar-method gauss with cache;
+ *   - numpy reductions as measured on numpy 2.2.6 (x86-64 SSE2 baseline):
+ *       einsum('ij,ij->i'), einsum('ij,j->i'), einsum('ji,ki->kj'):  (p0 + p2) + p1
+ *       einsum('ij,ijk->ik'), einsum('ij,ki->kj'), linalg.norm:      (p0 + p1) + p2
+ *       np.dot((n,3),(3,)) via OpenBLAS dgemv:   fma(a2,b2, fma(a0,b0, a1*b1))
+ *   - np.cross component formulas, np.interp, np.round (half-to-even).
+ *
+ * Build: gcc -O2 -ffp-contract=off -fPIC -shared (see oracle/Makefile).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <stdio.h>
+#include <pthread.h>
+
+#include "../include/xicsrt_hip.h"
+
+/* ------------------------------------------------------------------------ */
+/* numpy legacy RandomState                                                   */
+/* ------------------------------------------------------------------------ */
+
+typedef struct {
+    uint32_t key[624];
+    int      pos;
+    int      has_gauss;
+    double   gauss;
+} mt_t;
+
+/* np.random.seed(int) -> mt19937_seed / init_genrand (xicsrt_raytrace.py:111) */
+static void mt_seed(mt_t* s, uint32_t seed)
+{
+    for (int i = 0; i < 624; i++) {
+        s->key[i] = seed;
+        seed = 1812433253u * (seed ^ (seed >> 30)) + (uint32_t)(i + 1);
+    }
+    s->pos = 624;
+    s->has_gauss = 0;
+    s->gauss = 0.0;
+}
+
+static void mt_regen(mt_t* s)
+{
+    uint32_t* mt = s->key;
+    int i;
+    uint32_t y;
+    for (i = 0; i < 624 - 397; i++) {
+        y = (mt[i] & 0x80000000u) | (mt[i + 1] & 0x7fffffffu);
+        mt[i] = mt[i + 397] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    for (; i < 623; i++) {
+        y = (mt[i] & 0x80000000u) | (mt[i + 1] & 0x7fffffffu);
+        mt[i] = mt[i + (397 - 624)] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    y = (mt[623] & 0x80000000u) | (mt[0] & 0x7fffffffu);
+    mt[623] = mt[396] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    s->pos = 0;
+}
+
+static uint32_t mt_u32(mt_t* s)
+{
+    if (s->pos == 624) mt_regen(s);
+    uint32_t y = s->key[s->pos++];
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+/* genrand_res53 */
+static double mt_double(mt_t* s)
+{
+    uint32_t a = mt_u32(s) >> 5, b = mt_u32(s) >> 6;
+    return (a * 67108864.0 + b) / 9007199254740992.0;
+}
+
+/* legacy_gauss: polar Box-Muller with a cached second value */
+static double mt_gauss(mt_t* s)
+{
+    if (s->has_gauss) {
+        double t = s->gauss;
+        s->has_gauss = 0;
+        s->gauss = 0.0;
+        return t;
+    }
+    double f, x1, x2, r2;
+    do {
+        x1 = 2.0 * mt_double(s) - 1.0;
+        x2 = 2.0 * mt_double(s) - 1.0;
+        r2 = x1 * x1 + x2 * x2;
+    } while (r2 >= 1.0 || r2 == 0.0);
+    f = sqrt(-2.0 * log(r2) / r2);
+    s->gauss = f * x1;
+    s->has_gauss = 1;
+    return f * x2;
+}
+
+/* ------------------------------------------------------------------------ */
+/* small numeric helpers with numpy's evaluation order                        */
+/* ------------------------------------------------------------------------ */
+
+/* einsum('ij,ij->i') and friends on 3-vectors: SSE2 2-lane accumulate then tail */
+static inline double dot_e(const double a[3], const double b[3])
+{
+    return (a[0] * b[0] + a[2] * b[2]) + a[1] * b[1];
+}
+/* np.linalg.norm(axis=1) / einsum over a strided middle index */
+static inline double dot_n(const double a[3], const double b[3])
+{
+    return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2];
+}
+/* np.dot((n,3),(3,)) through OpenBLAS dgemv on the build machine */
+static inline double dot_blas(const double a[3], const double b[3])
+{
+    return fma(a[2], b[2], fma(a[0], b[0], a[1] * b[1]));
+}
+static inline double norm3(const double a[3]) { return sqrt(dot_n(a, a)); }
+/* np.cross */
+static inline void cross3(const double a[3], const double b[3], double c[3])
+{
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+/* GeometryObject.vector_to_local: einsum('ji,ki->kj') (_GeometryObject.py:163) */
+static inline void to_local(const double R[9], const double v[3], double out[3])
+{
+    for (int j = 0; j < 3; j++) out[j] = dot_e(&R[3 * j], v);
+}
+/* GeometryObject.vector_to_external: einsum('ij,ki->kj') (_GeometryObject.py:149) */
+static inline void to_external(const double R[9], const double v[3], double out[3])
+{
+    for (int j = 0; j < 3; j++)
+        out[j] = (R[0 + j] * v[0] + R[3 + j] * v[1]) + R[6 + j] * v[2];
+}
+
+/* np.interp(x, xp, fp) */
+static double np_interp(double x, const double* xp, const double* fp, int n)
+{
+    if (x != x) return x;
+    if (x < xp[0]) return fp[0];
+    if (x > xp[n - 1]) return fp[n - 1];
+    int lo = 0, hi = n - 1;       /* find j with xp[j] <= x < xp[j+1] */
+    while (hi - lo > 1) {
+        int mid = (lo + hi) / 2;
+        if (x >= xp[mid]) lo = mid; else hi = mid;
+    }
+    int j = lo;
+    if (x == xp[n - 1]) return fp[n - 1];
+    if (xp[j] == x) return fp[j];
+    double slope = (fp[j + 1] - fp[j]) / (xp[j + 1] - xp[j]);
+    double r = slope * (x - xp[j]) + fp[j];
+    if (r != r) {
+        r = slope * (x - xp[j + 1]) + fp[j + 1];
+        if (r != r && fp[j] == fp[j + 1]) r = fp[j];
+    }
+    return r;
+}
+
+/* ------------------------------------------------------------------------ */
+/* ray arrays (objects/_RayArray.py:12; 'weight' added at _XicsrtSourceGeneric.py:215) */
+/* ------------------------------------------------------------------------ */
+
+typedef struct {
+    int64_t  n;
+    double*  o;     /* [n][3] */
+    double*  d;     /* [n][3] */
+    double*  wl;    /* [n]    */
+    double*  wt;    /* [n]    */
+    uint8_t* mask;  /* [n]    */
+    uint8_t* prev;  /* [n] mask before the current optic            */
+    uint8_t* hit;   /* [n] ray had an intersection at this optic    */
+    /* scratch */
+    double*  x;     /* [n][3] intersection */
+    double*  nrm;   /* [n][3] normal       */
+    double*  loc;   /* [n][3] local coords */
+    double*  tmp;   /* [5n]                */
+} rays_t;
+
+static int rays_alloc(rays_t* r, int64_t n)
+{
+    memset(r, 0, sizeof(*r));
+    r->n = n;
+    size_t m = (size_t)(n > 0 ? n : 1);
+    r->o = malloc(m * 3 * sizeof(double));
+    r->d = malloc(m * 3 * sizeof(double));
+    r->wl = malloc(m * sizeof(double));
+    r->wt = malloc(m * sizeof(double));
+    r->mask = malloc(m);
+    r->prev = malloc(m);
+    r->hit = malloc(m);
+    r->x = malloc(m * 3 * sizeof(double));
+    r->nrm = malloc(m * 3 * sizeof(double));
+    r->loc = malloc(m * 3 * sizeof(double));
+    r->tmp = malloc(m * 5 * sizeof(double));
+    return (r->o && r->d && r->wl && r->wt && r->mask && r->prev && r->hit && r->x && r->nrm && r->loc && r->tmp) ? 0 : -1;
+}
+static void rays_free(rays_t* r)
+{
+    free(r->o); free(r->d); free(r->wl); free(r->wt); free(r->mask); free(r->prev); free(r->hit);
+    free(r->x); free(r->nrm); free(r->loc); free(r->tmp);
+}
+
+/* ------------------------------------------------------------------------ */
+/* source                                                                     */
+/* ------------------------------------------------------------------------ */
+
+/* np.random.uniform(low, high, n): low + (high-low)*d, array-sequential */
+static void fill_uniform(mt_t* mt, double low, double range, double* out, int64_t n)
+{
+    for (int64_t i = 0; i < n; i++) out[i] = low + range * mt_double(mt);
+}
+
+/* tools/xicsrt_spread.py:80-339 -- local unit vectors about +z */
+static void vector_distribution(const xrt_source_t* s, mt_t* mt, double* lv /*[n][3]*/,
+                                double* t0, double* t1, int64_t n)
+{
+    switch (s->angular_dist) {
+    case XRT_ANG_ISOTROPIC:
+        /* xicsrt_spread.py:102-108 */
+        fill_uniform(mt, s->ang[0], 1.0 - s->ang[0], t0, n);
+        fill_uniform(mt, 0.0, s->two_pi - 0.0, t1, n);
+        for (int64_t i = 0; i < n; i++) {
+            double z = t0[i], phi = t1[i];
+            double st = sqrt(1.0 - z * z);
+            lv[3 * i + 0] = st * cos(phi);
+            lv[3 * i + 1] = st * sin(phi);
+            lv[3 * i + 2] = z;
+        }
+        break;
+    case XRT_ANG_FLAT:
+        /* xicsrt_spread.py:235-243 */
+        fill_uniform(mt, 0.0, s->ang[0] - 0.0, t0, n);
+        fill_uniform(mt, 0.0, s->two_pi - 0.0, t1, n);
+        for (int64_t i = 0; i < n; i++) {
+            double r = sqrt(t0[i]);
+            double a1 = t1[i], a0 = atan(r);
+            lv[3 * i + 0] = cos(a1) * sin(a0);
+            lv[3 * i + 1] = sin(a1) * sin(a0);
+            lv[3 * i + 2] = cos(a0);
+        }
+        break;
+    case XRT_ANG_FLAT_XY:
+        /* xicsrt_spread.py:281-292 */
+        fill_uniform(mt, s->ang[0], s->ang[1] - s->ang[0], t0, n);
+        fill_uniform(mt, s->ang[2], s->ang[3] - s->ang[2], t1, n);
+        for (int64_t i = 0; i < n; i++) {
+            double x = t0[i], y = t1[i];
+            double a0 = atan(sqrt(x * x + y * y));
+            double a1 = atan2(y, x);
+            lv[3 * i + 0] = cos(a1) * sin(a0);
+            lv[3 * i + 1] = sin(a1) * sin(a0);
+            lv[3 * i + 2] = cos(a0);
+        }
+        break;
+    case XRT_ANG_ISOTROPIC_XY: {
+        /* xicsrt_spread.py:173-194: isotropic batches of n, filtered, until n kept */
+        int64_t filled = 0;
+        while (filled < n) {
+            fill_uniform(mt, s->ang[0], 1.0 - s->ang[0], t0, n);
+            fill_uniform(mt, 0.0, s->two_pi - 0.0, t1, n);
+            for (int64_t i = 0; i < n && filled < n; i++) {
+                double z = t0[i], phi = t1[i];
+                double st = sqrt(1.0 - z * z);
+                double vx = st * cos(phi), vy = st * sin(phi), vz = z;
+                double ax = vx / sqrt(vx * vx + vz * vz);
+                double ay = vy / sqrt(vy * vy + vz * vz);
+                int ok = (ax > s->ang[1]) && (ax <= s->ang[2]) && (ay > s->ang[3]) && (ay <= s->ang[4]);
+                if (ok) {
+                    lv[3 * filled + 0] = vx; lv[3 * filled + 1] = vy; lv[3 * filled + 2] = vz;
+                    filled++;
+                }
+            }
+        }
+        break; }
+    }
+}
+
+/* sources/_XicsrtSourceGeneric.py:198-227 */
+static void generate_rays(const xrt_source_t* s, mt_t* mt, rays_t* r)
+{
+    const int64_t n = r->n;
+    const double* R = s->orientation;
+    const double* xa = &R[0];
+    const double* ya = &R[3];
+    const double* za = &R[6];
+    double* t = r->tmp;
+
+    /* generate_origin (_XicsrtSourceGeneric.py:229-255) */
+    if (s->spatial_dist == XRT_SPATIAL_UNIFORM) {
+        for (int k = 0; k < 3; k++) {
+            double low = -1.0 * s->size[k] / 2.0, high = s->size[k] / 2.0;
+            fill_uniform(mt, low, high - low, t + k * n, n);
+        }
+    } else {
+        /* np.random.multivariate_normal(mean, cov, n): standard normals row-major,
+         * times the SVD factor the host computed (s->spatial_A), plus mean 0 */
+        for (int64_t i = 0; i < n; i++) {
+            double z[3];
+            for (int k = 0; k < 3; k++) z[k] = mt_gauss(mt);
+            for (int k = 0; k < 3; k++) {
+                double v = 0.0;
+                for (int j = 0; j < 3; j++) v += z[j] * s->spatial_A[3 * j + k];
+                t[k * n + i] = v + 0.0;
+            }
+        }
+    }
+    for (int64_t i = 0; i < n; i++)
+        for (int k = 0; k < 3; k++)
+            r->o[3 * i + k] = ((s->origin[k] + t[0 * n + i] * xa[k]) + t[1 * n + i] * ya[k]) + t[2 * n + i] * za[k];
+
+    /* generate_direction -> make_normal (:262-266, Directed :46-50, Focused :40-44) */
+    double* nv = r->nrm;
+    for (int64_t i = 0; i < n; i++) {
+        double a[3];
+        if (s->kind == XRT_SRC_FOCUSED)
+            for (int k = 0; k < 3; k++) a[k] = s->axis[k] - r->o[3 * i + k];
+        else
+            for (int k = 0; k < 3; k++) a[k] = s->axis[k];
+        double m = norm3(a);
+        for (int k = 0; k < 3; k++) nv[3 * i + k] = a[k] / m;
+    }
+    /* random_direction (:268-293) */
+    double* lv = r->loc;
+    vector_distribution(s, mt, lv, t, t + n, n);
+    for (int64_t i = 0; i < n; i++) {
+        const double* nn = &nv[3 * i];
+        double c1[3], c2[3], o1[3], o2[3];
+        cross3(nn, xa, c1);
+        cross3(nn, za, c2);
+        for (int k = 0; k < 3; k++) o1[k] = c1[k] + c2[k];
+        double m1 = norm3(o1);
+        for (int k = 0; k < 3; k++) o1[k] /= m1;
+        cross3(nn, o1, o2);
+        double m2 = norm3(o2);
+        for (int k = 0; k < 3; k++) o2[k] /= m2;
+        const double* l = &lv[3 * i];
+        for (int k = 0; k < 3; k++)
+            r->d[3 * i + k] = (l[0] * o2[k] + l[1] * o1[k]) + l[2] * nn[k];
+    }
+
+    /* generate_wavelength (:295-319) */
+    switch (s->wavelength_dist) {
+    case XRT_WL_CONST:
+        for (int64_t i = 0; i < n; i++) r->wl[i] = 1.0 * s->wavelength;
+        break;
+    case XRT_WL_UNIFORM:
+        fill_uniform(mt, s->wl_a, s->wl_b, r->wl, n);
+        break;
+    case XRT_WL_NORMAL:     /* np.random.normal(loc, sigma, n) (:366) */
+        for (int64_t i = 0; i < n; i++) r->wl[i] = s->wavelength + s->wl_a * mt_gauss(mt);
+        break;
+    case XRT_WL_VOIGT:      /* tools/xicsrt_voigt.py:127-129, then += wavelength (:353) */
+        fill_uniform(mt, s->wl_a, s->wl_b, t, n);
+        for (int64_t i = 0; i < n; i++)
+            r->wl[i] = np_interp(t[i], s->voigt_cdf, s->voigt_x, s->voigt_n) + s->wavelength;
+        break;
+    }
+    if (s->has_velocity) {      /* Doppler (:314-317) */
+        for (int64_t i = 0; i < n; i++) {
+            double v = dot_e(s->velocity, &r->d[3 * i]);
+            r->wl[i] *= 1.0 - (v / s->light_speed);
+        }
+    }
+    for (int64_t i = 0; i < n; i++) { r->wt[i] = 1.0; r->mask[i] = 1; }
+}
+
+/* ------------------------------------------------------------------------ */
+/* optics                                                                     */
+/* ------------------------------------------------------------------------ */
+
+/* optics/_ShapeObject.py:79 */
+static inline void location_from_distance(const double* o, const double* d, double t, double* x)
+{
+    for (int k = 0; k < 3; k++) x[k] = o[k] + d[k] * t;
+}
+
+/* optics/_ShapePlane.py:25-62 */
+static void intersect_plane(const xrt_optic_t* op, rays_t* r)
+{
+    const double* za = &op->orientation[6];
+    for (int64_t i = 0; i < r->n; i++) {
+        if (!r->mask[i]) continue;
+        const double* o = &r->o[3 * i];
+        const double* d = &r->d[3 * i];
+        double t;
+        if (op->flags & XRT_F_TRACE_LOCAL) {
+            const double ez[3] = {0.0, 0.0, 1.0};
+            double v[3] = {0.0 - o[0], 0.0 - o[1], 0.0 - o[2]};
+            t = dot_blas(v, ez) / dot_blas(d, ez);
+        } else {
+            double v[3] = {op->origin[0] - o[0], op->origin[1] - o[1], op->origin[2] - o[2]};
+            t = dot_blas(v, za) / dot_blas(d, za);
+        }
+        if (!(t >= 0.0)) { r->mask[i] = 0; continue; }
+        location_from_distance(o, d, t, &r->x[3 * i]);
+        for (int k = 0; k < 3; k++) r->nrm[3 * i + k] = za[k];
+    }
+}
+
+/* optics/_ShapeSphere.py:37-106 */
+static void intersect_sphere(const xrt_optic_t* op, rays_t* r)
+{
+    for (int64_t i = 0; i < r->n; i++) {
+        if (!r->mask[i]) continue;
+        const double* o = &r->o[3 * i];
+        const double* d = &r->d[3 * i];
+        double L[3] = {op->center[0] - o[0], op->center[1] - o[1], op->center[2] - o[2]};
+        double t_ca = dot_e(L, d);
+        double dd = sqrt(dot_e(L, L) - t_ca * t_ca);
+        if (!(dd <= op->radius)) { r->mask[i] = 0; continue; }
+        double t_hc = sqrt(op->radius2 - dd * dd);
+        double t0 = t_ca - t_hc, t1 = t_ca + t_hc, t;
+        if (op->flags & XRT_F_CONVEX) t = (t0 < t1) ? t0 : t1;
+        else                          t = (t0 > t1) ? t0 : t1;
+        double* x = &r->x[3 * i];
+        location_from_distance(o, d, t, x);
+        double c[3] = {op->center[0] - x[0], op->center[1] - x[1], op->center[2] - x[2]};
+        double m = norm3(c);
+        for (int k = 0; k < 3; k++) r->nrm[3 * i + k] = c[k] / m;
+    }
+}
+
+/* optics/_ShapeCylinder.py:52-133 */
+static void intersect_cylinder(const xrt_optic_t* op, rays_t* r)
+{
+    const double* pa = op->center;
+    const double* va = &op->orientation[0];
+    for (int64_t i = 0; i < r->n; i++) {
+        if (!r->mask[i]) continue;
+        const double* o = &r->o[3 * i];
+        const double* d = &r->d[3 * i];
+        double dp[3] = {o[0] - pa[0], o[1] - pa[1], o[2] - pa[2]};
+        double dDva = dot_e(d, va), dpva = dot_e(dp, va);
+        double A1[3], B1[3];
+        for (int k = 0; k < 3; k++) { A1[k] = d[k] - dDva * va[k]; B1[k] = dp[k] - dpva * va[k]; }
+        double A = dot_e(A1, A1);
+        double B = 2.0 * dot_e(A1, B1);
+        double C = dot_e(B1, B1) - op->radius2;
+        double dis = B * B - 4.0 * A * C;
+        if (!(dis >= 0.0)) { r->mask[i] = 0; continue; }
+        double sq = sqrt(dis);
+        double t0 = (-B - sq) / (2.0 * A), t1 = (-B + sq) / (2.0 * A), t;
+        if (op->flags & XRT_F_CONVEX) t = (t0 < t1) ? t0 : t1;
+        else                          t = (t0 > t1) ? t0 : t1;
+        double* x = &r->x[3 * i];
+        location_from_distance(o, d, t, x);
+        double q[3] = {pa[0] - x[0], pa[1] - x[1], pa[2] - x[2]};
+        double dummy = dot_e(q, va);
+        double c[3];
+        for (int k = 0; k < 3; k++) c[k] = (pa[k] - dummy * va[k]) - x[k];
+        double m = norm3(c);
+        for (int k = 0; k < 3; k++) r->nrm[3 * i + k] = c[k] / m;
+    }
+}
+
+/* tools/xicsrt_aperture.py:108-204: single shape test on local coordinates */
+static int aperture_shape(const xrt_aperture_t* a, const double* X)
+{
+    double x = X[0], y = X[1];
+    switch (a->shape) {
+    case XRT_AP_NONE: return 1;
+    case XRT_AP_CIRCLE: {
+        double dx = x - a->origin[0], dy = y - a->origin[1];
+        return (dx * dx + dy * dy) < a->size[0] * a->size[0]; }
+    case XRT_AP_SQUARE:
+        return (fabs(x - a->origin[0]) < a->size[0] / 2.0) && (fabs(y - a->origin[1]) < a->size[0] / 2.0);
+    case XRT_AP_RECTANGLE:
+        return (fabs(x - a->origin[0]) < a->size[0] / 2.0) && (fabs(y - a->origin[1]) < a->size[1] / 2.0);
+    case XRT_AP_ELLIPSE: {
+        double ex = (x - a->origin[0]) / a->size[0], ey = (y - a->origin[1]) / a->size[1];
+        return (ex * ex + ey * ey) < 1.0; }
+    case XRT_AP_TRIANGLE: {
+        /* tools/xicsrt_math.py:290-306 */
+        const double* v = a->vertices;
+        double p0x = v[0], p0y = v[1], p1x = v[2], p1y = v[3], p2x = v[4], p2y = v[5];
+        double area = 0.5 * (-p1y * p2x + p0y * (-p1x + p2x) + p0x * (p1y - p2y) + p1x * p2y);
+        double ia = 1.0 / (2.0 * area);
+        double A = ia * (p0y * p2x - p0x * p2y + (p2y - p0y) * x + (p0x - p2x) * y);
+        double B = ia * (p0x * p1y - p0y * p1x + (p0y - p1y) * x + (p1x - p0x) * y);
+        double Cc = 1.0 - A - B;
+        return (A >= 0.0) && (B >= 0.0) && (Cc >= 0.0); }
+    }
+    return 1;
+}
+
+/* optics/_TraceObject.py:180-232, tools/xicsrt_aperture.py:13-47 */
+static void check_bounds(const xrt_optic_t* op, rays_t* r)
+{
+    for (int64_t i = 0; i < r->n; i++) {
+        if (!r->mask[i]) continue;
+        double* loc = &r->loc[3 * i];
+        const double* x = &r->x[3 * i];
+        if (op->flags & XRT_F_TRACE_LOCAL) {
+            for (int k = 0; k < 3; k++) loc[k] = x[k];
+        } else {
+            double v[3] = {x[0] - op->origin[0], x[1] - op->origin[1], x[2] - op->origin[2]};
+            to_local(op->orientation, v, loc);
+        }
+        int m = 1;
+        if (op->flags & XRT_F_CHECK_SIZE) {
+            if ((op->flags & XRT_F_HAS_XSIZE) && !(fabs(loc[0]) < op->half_size[0])) m = 0;
+            if ((op->flags & XRT_F_HAS_YSIZE) && !(fabs(loc[1]) < op->half_size[1])) m = 0;
+            if ((op->flags & XRT_F_HAS_ZSIZE) && !(fabs(loc[2]) < op->half_size[2])) m = 0;
+        }
+        if (m && (op->flags & XRT_F_CHECK_APERTURE) && op->n_apertures > 0) {
+            int out = 1;
+            for (int a = 0; a < op->n_apertures; a++) {
+                int t = aperture_shape(&op->apertures[a], loc);
+                switch (op->apertures[a].logic) {
+                case XRT_LOGIC_AND:  out = out && t; break;
+                case XRT_LOGIC_NOT:  out = out && !t; break;
+                case XRT_LOGIC_OR:   out = out || t; break;
+                case XRT_LOGIC_NAND: out = !(out && t); break;
+                case XRT_LOGIC_NOR:  out = !(out || t); break;
+                case XRT_LOGIC_XOR:  out = (out != t); break;
+                case XRT_LOGIC_XNOR: out = !(out != t); break;
+                }
+            }
+            m = out;
+        }
+        r->mask[i] = (uint8_t)m;
+    }
+}
+
+/* optics/_InteractCrystal.py:96-196: Bragg test, draws in original ray order */
+static void angle_check(const xrt_optic_t* op, rays_t* r, mt_t* mt)
+{
+    for (int64_t i = 0; i < r->n; i++) {
+        if (!r->mask[i]) continue;
+        const double* d = &r->d[3 * i];
+        const double* nn = &r->nrm[3 * i];
+        double bragg = asin(r->wl[i] / op->two_d);
+        double neg[3] = {-1.0 * nn[0], -1.0 * nn[1], -1.0 * nn[2]};
+        double dt = fabs(dot_e(d, neg));
+        double inc = op->half_pi - acos(dt / norm3(d));
+        double p;
+        if (op->rocking_type == XRT_ROCKING_STEP) {
+            p = (fabs(inc - bragg) <= op->rocking_half_fwhm) ? 1.0 : 0.0;
+        } else {
+            double df = inc - bragg;
+            p = exp(-(df * df) / op->rocking_2sigma2);
+        }
+        p *= op->reflectivity;
+        double test = 0.0 + (1.0 - 0.0) * mt_double(mt);
+        if (!(p >= test)) r->mask[i] = 0;
+    }
+}
+
+/* optics/_TraceObject.py:157-171 + Interact* */
+static void trace_optic(const xrt_optic_t* op, rays_t* r, mt_t* mt)
+{
+    const int local = (op->flags & XRT_F_TRACE_LOCAL) != 0;
+    if (local) {    /* ray_to_local (_GeometryObject.py:126-135), all rays */
+        for (int64_t i = 0; i < r->n; i++) {
+            double v[3] = {r->o[3 * i] - op->origin[0], r->o[3 * i + 1] - op->origin[1], r->o[3 * i + 2] - op->origin[2]};
+            double t[3];
+            to_local(op->orientation, v, t);
+            memcpy(&r->o[3 * i], t, sizeof(t));
+            to_local(op->orientation, &r->d[3 * i], t);
+            memcpy(&r->d[3 * i], t, sizeof(t));
+        }
+    }
+    memcpy(r->prev, r->mask, (size_t)r->n);
+    switch (op->shape) {
+    case XRT_SHAPE_PLANE:    intersect_plane(op, r); break;
+    case XRT_SHAPE_SPHERE:   intersect_sphere(op, r); break;
+    case XRT_SHAPE_CYLINDER: intersect_cylinder(op, r); break;
+    }
+    memcpy(r->hit, r->mask, (size_t)r->n);
+    check_bounds(op, r);
+    if (op->interact == XRT_INTERACT_CRYSTAL && (op->flags & XRT_F_CHECK_BRAGG))
+        angle_check(op, r, mt);
+    for (int64_t i = 0; i < r->n; i++) {
+        /* InteractObject.interact / InteractMirror.reflect_vectors (_InteractMirror.py:29-42):
+         * O[:] = xloc for every ray (NaN where there was no intersection) */
+        double* o = &r->o[3 * i];
+        double* d = &r->d[3 * i];
+        const double* x = &r->x[3 * i];
+        const double* nn = &r->nrm[3 * i];
+        if (!r->mask[i]) {
+            if (r->prev[i]) for (int k = 0; k < 3; k++) o[k] = r->hit[i] ? x[k] : NAN;
+            continue;
+        }
+        for (int k = 0; k < 3; k++) o[k] = x[k];
+        if (op->interact != XRT_INTERACT_NONE) {
+            double dt = dot_e(d, nn);
+            for (int k = 0; k < 3; k++) d[k] = d[k] - 2.0 * (dt * nn[k]);
+        }
+    }
+    if (local) {    /* ray_to_external (_GeometryObject.py:113-124) */
+        for (int64_t i = 0; i < r->n; i++) {
+            double t[3];
+            to_external(op->orientation, &r->o[3 * i], t);
+            for (int k = 0; k < 3; k++) r->o[3 * i + k] = t[k] + op->origin[k];
+            to_external(op->orientation, &r->d[3 * i], t);
+            memcpy(&r->d[3 * i], t, sizeof(t));
+        }
+    }
+}
+
+/* optics/_TraceObject.py:234-293 */
+static void make_image(const xrt_optic_t* op, const rays_t* r, uint64_t* img)
+{
+    if (!(op->flags & XRT_F_IMAGE) || !img) return;
+    for (int64_t i = 0; i < r->n; i++) {
+        if (!r->mask[i]) continue;
+        double v[3] = {r->o[3 * i] - op->origin[0], r->o[3 * i + 1] - op->origin[1], r->o[3 * i + 2] - op->origin[2]};
+        double loc[3];
+        to_local(op->orientation, v, loc);
+        double cx = rint(loc[0] / op->pixel_size + op->pixel_xoff);
+        double cy = rint(loc[1] / op->pixel_size + op->pixel_yoff);
+        if (!(cx >= 0.0 && cx < (double)op->pixel_nx && cy >= 0.0 && cy < (double)op->pixel_ny)) continue;
+        img[op->image_offset + (int64_t)cx * op->pixel_ny + (int64_t)cy] += 1;
+    }
+}
+
+static void save_history(const rays_t* r, int e, double* hist, uint8_t* hmask)
+{
+    const int64_t n = r->n;
+    for (int64_t i = 0; i < n; i++) {
+        hmask[(int64_t)e * n + i] = r->mask[i];
+        if (!r->mask[i] && !(e > 0 && r->prev[i])) continue;   /* alive, or died at this element */
+        double* h = hist + (int64_t)e * XRT_HIST_COMPONENTS * n;
+        for (int k = 0; k < 3; k++) { h[k * n + i] = r->o[3 * i + k]; h[(3 + k) * n + i] = r->d[3 * i + k]; }
+        h[6 * n + i] = r->wl[i];
+        h[7 * n + i] = r->wt[i];
+    }
+}
+
+/* xicsrt_raytrace.raytrace_single (xicsrt_raytrace.py:87-175), keep_history=False stream */
+static int run_single(const xrt_scene_t* sc, mt_t* mtp, int n_iter,
+                      uint64_t* num_out, uint64_t* images, double* hist, uint8_t* hmask)
+{
+    mt_t mt = *mtp;
+    rays_t r;
+    if (rays_alloc(&r, sc->source.intensity)) { rays_free(&r); return -2; }
+    for (int it = 0; it < n_iter; it++) {
+        generate_rays(&sc->source, &mt, &r);
+        num_out[0] += (uint64_t)r.n;
+        if (hist) save_history(&r, 0, hist, hmask);
+        for (int e = 0; e < sc->n_optics; e++) {
+            const xrt_optic_t* op = &sc->optics[e];
+            trace_optic(op, &r, &mt);
+            uint64_t c = 0;
+            for (int64_t i = 0; i < r.n; i++) c += r.mask[i];
+            num_out[e + 1] += c;
+            if (hist) save_history(&r, e + 1, hist, hmask);
+            make_image(op, &r, images);
+        }
+    }
+    *mtp = mt;
+    rays_free(&r);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* exported                                                                   */
+/* ------------------------------------------------------------------------ */
+
+int xrt_oracle_abi_version(void) { return XRT_ABI_VERSION; }
+size_t xrt_oracle_sizeof_scene(void) { return sizeof(xrt_scene_t); }
+
+/* known-answer hooks for the RNG restatement */
+void xrt_oracle_mt_u32(uint32_t seed, uint32_t* out, int64_t n)
+{
+    mt_t mt; mt_seed(&mt, seed);
+    for (int64_t i = 0; i < n; i++) out[i] = mt_u32(&mt);
+}
+void xrt_oracle_mt_double(uint32_t seed, double* out, int64_t n)
+{
+    mt_t mt; mt_seed(&mt, seed);
+    for (int64_t i = 0; i < n; i++) out[i] = mt_double(&mt);
+}
+void xrt_oracle_mt_gauss(uint32_t seed, double* out, int64_t n)
+{
+    mt_t mt; mt_seed(&mt, seed);
+    for (int64_t i = 0; i < n; i++) out[i] = mt_gauss(&mt);
+}
+
+typedef struct {
+    const xrt_scene_t* sc;
+    const uint32_t* seeds;
+    int n_runs, n_iter, tid, n_threads;
+    uint64_t* num_out;
+    uint64_t* images;
+    int status;
+} job_t;
+
+static void* worker(void* p)
+{
+    job_t* j = (job_t*)p;
+    for (int r = j->tid; r < j->n_runs; r += j->n_threads) {
+        mt_t mt;
+        mt_seed(&mt, j->seeds[r]);
+        int st = run_single(j->sc, &mt, j->n_iter, j->num_out, j->images, NULL, NULL);
+        if (st) { j->status = st; break; }
+    }
+    return NULL;
+}
+
+/*
+ * xicsrt_raytrace.raytrace / xicsrt_multiprocessing.raytrace
+ * (xicsrt_raytrace.py:28-84, xicsrt_multiprocessing.py:12-81): runs are
+ * independent; `threads` workers take runs round-robin (Pool analogue) with
+ * private accumulators that are summed at the end (combine_raytrace :328-356).
+ * All pointers are host memory.  num_out has n_optics+1 entries.
+ */
+int xrt_oracle_trace(const xrt_scene_t* sc, const uint32_t* seeds, int32_t n_runs, int32_t n_iter,
+                     uint64_t* num_out, uint64_t* images, int32_t threads)
+{
+    if (threads < 1) threads = 1;
+    if (threads > n_runs) threads = n_runs > 0 ? n_runs : 1;
+    const int ne = sc->n_optics + 1;
+    const int64_t nb = sc->image_bins;
+    job_t* jobs = calloc((size_t)threads, sizeof(job_t));
+    pthread_t* th = calloc((size_t)threads, sizeof(pthread_t));
+    int status = 0;
+    for (int t = 0; t < threads; t++) {
+        jobs[t].sc = sc; jobs[t].seeds = seeds; jobs[t].n_runs = n_runs; jobs[t].n_iter = n_iter;
+        jobs[t].tid = t; jobs[t].n_threads = threads;
+        jobs[t].num_out = calloc((size_t)ne, sizeof(uint64_t));
+        jobs[t].images = images ? calloc((size_t)(nb > 0 ? nb : 1), sizeof(uint64_t)) : NULL;
+    }
+    if (threads == 1) worker(&jobs[0]);
+    else {
+        for (int t = 0; t < threads; t++) pthread_create(&th[t], NULL, worker, &jobs[t]);
+        for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+    }
+    for (int t = 0; t < threads; t++) {
+        if (jobs[t].status) status = jobs[t].status;
+        for (int e = 0; e < ne; e++) num_out[e] += jobs[t].num_out[e];
+        if (images) for (int64_t b = 0; b < nb; b++) images[b] += jobs[t].images[b];
+        free(jobs[t].num_out); free(jobs[t].images);
+    }
+    free(jobs); free(th);
+    return status;
+}
+
+/* One iteration from an explicit generator state with the per-element history
+ * (Dispatcher deepcopy, _Dispatcher.py:162,187); layout as XRT_HIST_COMPONENTS in
+ * xicsrt_hip.h.  state_out receives the generator state after the iteration. */
+int xrt_oracle_trace_history(const xrt_scene_t* sc, const xrt_rng_state_t* state_in,
+                             uint64_t* num_out, uint64_t* images,
+                             double* rays, uint8_t* mask, xrt_rng_state_t* state_out)
+{
+    mt_t mt;
+    memcpy(mt.key, state_in->key, sizeof(mt.key));
+    mt.pos = state_in->pos; mt.has_gauss = state_in->has_gauss; mt.gauss = state_in->gauss;
+    int st = run_single(sc, &mt, 1, num_out, images, rays, mask);
+    if (state_out) {
+        memcpy(state_out->key, mt.key, sizeof(mt.key));
+        state_out->pos = mt.pos; state_out->has_gauss = mt.has_gauss; state_out->gauss = mt.gauss;
+    }
+    return st;
+}

@@ -1,0 +1,400 @@
+"""
+Scene flattener: initialised element objects -> the fixed-layout C structs of
+include/xicsrt_hip.h (ctypes mirrors below).
+
+All scalar set-up arithmetic is done here with NumPy in the same way the
+reference's setup()/initialize()/per-call preambles do it, so the device
+receives bit-identical constants:
+
+  source   cone axis / basis inputs        xicsrt/sources/_XicsrtSourceGeneric.py:262-292
+           cos(spread), tan(spread) ...    xicsrt/tools/xicsrt_spread.py:102,235,282,173-186
+           wavelength case analysis        xicsrt/sources/_XicsrtSourceGeneric.py:295-367
+           Voigt CDF table                 xicsrt/tools/xicsrt_voigt.py:30-83
+  optic    xsize/2 ...                     xicsrt/optics/_TraceObject.py:204-212
+           sphere / cylinder centre        xicsrt/optics/_ShapeSphere.py:37-43
+           2*d, fwhm/2, 2*sigma**2, pi/2   xicsrt/optics/_InteractCrystal.py:110-149
+           pixel grid                      xicsrt/optics/_TraceObject.py:104-131,268-270
+           aperture defaults               xicsrt/tools/xicsrt_aperture.py:83-104
+"""
+import ctypes as C
+
+import numpy as np
+
+XRT_ABI_VERSION = 3
+XRT_MAX_OPTICS = 16
+XRT_MAX_APERTURES = 8
+XRT_HIST_COMPONENTS = 8
+
+SRC_KIND = {'zaxis': 0, 'direction': 1, 'target': 2}
+SPATIAL = {'uniform': 0, 'gaussian': 1}
+ANGULAR = {'isotropic': 0, 'isotropic_xy': 1, 'flat': 2, 'flat_xy': 3}
+WL_CONST, WL_UNIFORM, WL_NORMAL, WL_VOIGT = 0, 1, 2, 3
+SHAPE = {'plane': 0, 'sphere': 1, 'cylinder': 2, 'torus': 3}
+INTERACT = {'none': 0, 'mirror': 1, 'crystal': 2}
+ROCKING_STEP, ROCKING_GAUSS = 0, 1
+AP_SHAPE = {'none': 0, 'circle': 1, 'square': 2, 'rectangle': 3, 'ellipse': 4, 'triangle': 5}
+AP_LOGIC = {'and': 0, 'not': 1, 'or': 2, 'nand': 3, 'nor': 4, 'xor': 5, 'xnor': 6}
+
+F_CHECK_SIZE, F_CHECK_APERTURE = 1 << 0, 1 << 1
+F_HAS_XSIZE, F_HAS_YSIZE, F_HAS_ZSIZE = 1 << 2, 1 << 3, 1 << 4
+F_CONVEX, F_CHECK_BRAGG, F_IMAGE, F_TRACE_LOCAL = 1 << 5, 1 << 6, 1 << 7, 1 << 8
+
+
+class Aperture(C.Structure):
+    _fields_ = [('shape', C.c_int32), ('logic', C.c_int32),
+                ('origin', C.c_double * 2), ('size', C.c_double * 2),
+                ('vertices', C.c_double * 6)]
+
+
+class Source(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('spatial_dist', C.c_int32),
+                ('angular_dist', C.c_int32), ('wavelength_dist', C.c_int32),
+                ('intensity', C.c_int64),
+                ('origin', C.c_double * 3), ('orientation', C.c_double * 9),
+                ('size', C.c_double * 3), ('spatial_A', C.c_double * 9),
+                ('axis', C.c_double * 3), ('ang', C.c_double * 5),
+                ('two_pi', C.c_double), ('wavelength', C.c_double),
+                ('wl_a', C.c_double), ('wl_b', C.c_double),
+                ('has_velocity', C.c_int32), ('voigt_n', C.c_int32),
+                ('velocity', C.c_double * 3), ('light_speed', C.c_double),
+                ('voigt_cdf', C.POINTER(C.c_double)), ('voigt_x', C.POINTER(C.c_double))]
+
+
+class Optic(C.Structure):
+    _fields_ = [('shape', C.c_int32), ('interact', C.c_int32),
+                ('flags', C.c_int32), ('rocking_type', C.c_int32),
+                ('origin', C.c_double * 3), ('orientation', C.c_double * 9),
+                ('half_size', C.c_double * 3),
+                ('radius', C.c_double), ('radius2', C.c_double), ('center', C.c_double * 3),
+                ('torus_major', C.c_double), ('torus_minor', C.c_double),
+                ('torus_root', C.c_int32), ('n_apertures', C.c_int32),
+                ('two_d', C.c_double), ('reflectivity', C.c_double),
+                ('rocking_half_fwhm', C.c_double), ('rocking_2sigma2', C.c_double),
+                ('half_pi', C.c_double),
+                ('pixel_size', C.c_double), ('pixel_xoff', C.c_double), ('pixel_yoff', C.c_double),
+                ('pixel_nx', C.c_int32), ('pixel_ny', C.c_int32),
+                ('image_offset', C.c_int64),
+                ('apertures', Aperture * XRT_MAX_APERTURES)]
+
+
+class Scene(C.Structure):
+    _fields_ = [('source', Source), ('n_optics', C.c_int32), ('reserved', C.c_int32),
+                ('image_bins', C.c_int64), ('optics', Optic * XRT_MAX_OPTICS)]
+
+
+class RngState(C.Structure):
+    """numpy legacy RandomState: MT19937 key, position, cached gaussian."""
+    _fields_ = [('key', C.c_uint32 * 624), ('pos', C.c_int32), ('has_gauss', C.c_int32),
+                ('gauss', C.c_double)]
+
+
+class SceneError(NotImplementedError):
+    """The scene uses a feature the device path does not implement."""
+
+
+def _vec(dst, values):
+    values = np.asarray(values, dtype=np.float64).ravel()
+    if len(values) != len(dst):
+        raise ValueError('expected %d values, got %d' % (len(dst), len(values)))
+    for i, v in enumerate(values):
+        dst[i] = float(v)
+
+
+def _parse_spread_single(spread):
+    spread = np.array([spread]) if np.isscalar(spread) else np.asarray(spread)
+    if spread.ndim == 0:
+        spread = spread.reshape(1)
+    if len(spread) != 1:
+        raise Exception('Spread must be a scalar or one element array.')
+    return spread
+
+
+def _parse_spread_xy(spread):
+    spread = np.array([spread]) if np.isscalar(spread) else np.asarray(spread)
+    if spread.ndim == 0:
+        spread = spread.reshape(1)
+    if len(spread) == 1:
+        return [-spread[0], spread[0], -spread[0], spread[0]]
+    if len(spread) == 2:
+        return [-spread[0], spread[0], -spread[1], spread[1]]
+    if len(spread) == 4:
+        return [spread[0], spread[1], spread[2], spread[3]]
+    raise Exception('Spread must have 1, 2 or 3 elements. See docstring.')
+
+
+def voigt_cdf_table(gamma, sigma, gridsize=1000, cutoff=1e-5):
+    """Tabulated Voigt CDF on a variable-density grid (xicsrt_voigt.py:30-83); returns (x, cdf)."""
+    from scipy.special import wofz
+    gridsize_min = 100
+    fraction = 0.5
+    gauss_hwfm = np.sqrt(2.0 * np.log(1.0 / fraction)) * sigma
+    lorentz_hwfm = gamma * np.sqrt(1.0 / fraction - 1.0)
+    hwfm_max = np.sqrt(gauss_hwfm ** 2 + lorentz_hwfm ** 2)
+    min_spacing = hwfm_max / 5.0
+    value = gridsize_min / 2 * min_spacing
+    lorentz_cutoff = gamma * np.sqrt(1.0 / cutoff - 1.0)
+    gauss_cutoff = np.sqrt(-1 * sigma ** 2 * 2 * np.log(cutoff * sigma * np.sqrt(2 * np.pi)))
+    value_cutoff = max(lorentz_cutoff, gauss_cutoff)
+    base = np.exp(1 / 10 * np.log(value_cutoff / value))
+    bounds = np.linspace(-value, value, gridsize + 1)
+    bounds = bounds * base ** np.abs(bounds / value * 10)
+    cdf_x = (bounds[:-1] + bounds[1:]) / 2
+    z = (cdf_x - 0.0 + 1j * gamma) / np.sqrt(2) / sigma
+    cdf_y = wofz(z).real / np.sqrt(2 * np.pi) / sigma * 1.0
+    cdf = np.cumsum(cdf_y * (bounds[1:] - bounds[:-1]))
+    if np.sum((cdf > 0.25) & (cdf < 0.75)) < 3:
+        raise Exception('Voight CDF calculation does not have enough resolution.')
+    if np.max(cdf) < 0.99:
+        raise Exception('Voight CDF calculation domain too small.')
+    return bounds[1:], cdf
+
+
+def flatten_source(obj, out, keep):
+    """Fill a Source struct from an initialised XicsrtSource* object; `keep` pins host arrays."""
+    p = obj.param
+    out.kind = SRC_KIND[obj.cone_axis_rule]
+    sd = str(p['spatial_dist'])
+    if sd not in SPATIAL:
+        raise NotImplementedError(f"spatial_dist: {p['spatial_dist']} not implemented.")
+    out.spatial_dist = SPATIAL[sd]
+    ad = 'isotropic' if p['angular_dist'] is None else str(p['angular_dist']).lower()
+    if ad == 'gaussian':
+        # the reference raises NameError here (xicsrt_spread.py:55)
+        raise NameError("name 'vector_dist_gaussian' is not defined")
+    if ad not in ANGULAR:
+        raise Exception(f'Distribution "{ad}" is not known.')
+    out.angular_dist = ANGULAR[ad]
+    out.intensity = int(p['intensity'])
+    _vec(out.origin, obj.origin)
+    _vec(out.orientation, obj.orientation)
+    _vec(out.size, [p['xsize'], p['ysize'], p['zsize']])
+    _vec(out.spatial_A, np.zeros(9))
+    if sd == 'gaussian':
+        cov = [[p['xsize'] ** 2, 0, 0], [0, p['ysize'] ** 2, 0], [0, 0, p['zsize'] ** 2]]
+        sigma_to_fwhm = 2 * np.sqrt(2 * np.log(2))
+        cov = np.array(cov) / sigma_to_fwhm ** 2
+        # legacy multivariate_normal: x = standard_normal @ (sqrt(s)[:, None] * v)
+        (u, s, v) = np.linalg.svd(cov.astype(np.double))
+        _vec(out.spatial_A, np.sqrt(s)[:, None] * v)
+    axis = obj.cone_axis()
+    if axis is None:
+        raise Exception('source cone axis (%s) is not set' % obj.cone_axis_rule)
+    _vec(out.axis, axis)
+
+    spread = p['spread']
+    ang = np.zeros(5)
+    if ad == 'isotropic':
+        theta = _parse_spread_single(spread)
+        ang[0] = np.cos(theta)[0]
+    elif ad == 'flat':
+        theta = _parse_spread_single(spread)
+        ang[0] = np.tan(theta)[0]
+    elif ad == 'flat_xy':
+        ang[0:4] = np.tan(_parse_spread_xy(spread))
+    elif ad == 'isotropic_xy':
+        theta = _parse_spread_xy(spread)
+        theta_xmax = np.max(np.abs(theta[0:2]))
+        theta_ymax = np.max(np.abs(theta[2:]))
+        theta_max = np.arcsin(np.sqrt(np.sin(theta_xmax) ** 2 + np.sin(theta_ymax) ** 2))
+        ang[0] = np.cos(_parse_spread_single(theta_max))[0]
+        ang[1:5] = [np.sin(t) for t in theta]
+    _vec(out.ang, ang)
+    out.two_pi = float(2 * np.pi)
+
+    # wavelength: the reference's case analysis (_XicsrtSourceGeneric.py:295-367)
+    import scipy.constants as const
+    c = const.physical_constants['speed of light in vacuum'][0]
+    amu_kg = const.physical_constants['atomic mass unit-kilogram relationship'][0]
+    ev_J = const.physical_constants['electron volt-joule relationship'][0]
+    out.wavelength = float(p['wavelength'])
+    out.wl_a = out.wl_b = 0.0
+    out.voigt_n = 0
+    wtype = str.lower(p['wavelength_dist'])
+    if wtype == 'monochrome':
+        out.wavelength_dist = WL_CONST
+    elif wtype == 'uniform':
+        out.wavelength_dist = WL_UNIFORM
+        low, high = float(p['wavelength_range'][0]), float(p['wavelength_range'][1])
+        out.wl_a, out.wl_b = low, high - low
+    elif wtype == 'voigt':
+        if p['linewidth'] == 0.0 and p['temperature'] == 0.0:
+            out.wavelength_dist = WL_CONST
+        elif p['linewidth'] == 0.0:
+            out.wavelength_dist = WL_NORMAL
+            out.wl_a = float(np.sqrt(p['temperature'] / p['mass_number'] / amu_kg / c ** 2 * ev_J)
+                             * p['wavelength'])
+        else:
+            if p['temperature'] == 0.0:
+                p['temperature'] += 1.0     # reference quirk (_XicsrtSourceGeneric.py:339)
+            gamma = (p['linewidth'] * p['wavelength'] ** 2 / (4 * np.pi * c * 1e10))
+            sigma = (np.sqrt(p['temperature'] / p['mass_number'] / amu_kg / c ** 2 * ev_J)
+                     * p['wavelength'])
+            cdf_x, cdf = voigt_cdf_table(gamma, sigma)
+            cdf_x = np.ascontiguousarray(cdf_x, dtype=np.float64)
+            cdf = np.ascontiguousarray(cdf, dtype=np.float64)
+            keep.extend([cdf_x, cdf])
+            out.wavelength_dist = WL_VOIGT
+            lo, hi = float(np.min(cdf)), float(np.max(cdf))
+            out.wl_a, out.wl_b = lo, hi - lo
+            out.voigt_n = len(cdf)
+            out.voigt_cdf = cdf.ctypes.data_as(C.POINTER(C.c_double))
+            out.voigt_x = cdf_x.ctypes.data_as(C.POINTER(C.c_double))
+    else:
+        raise Exception(f'Wavelength distribution {wtype} unknown')
+    velocity = np.asarray(p['velocity'], dtype=np.float64)
+    out.has_velocity = int(not np.all(velocity == 0.0))
+    _vec(out.velocity, velocity)
+    out.light_speed = float(c)
+
+
+def _aperture_list(info):
+    if info is None:
+        return []
+    info = np.asarray(info)
+    if info.ndim == 0:
+        info = info.reshape(1)
+    return list(info)
+
+
+def flatten_optic(obj, out, image_offset):
+    """Fill an Optic struct from an initialised XicsrtOptic* object; returns bins used."""
+    p = obj.param
+    if obj.shape_kind not in SHAPE or obj.interact_kind not in INTERACT:
+        raise SceneError('optic %s is not implemented on the device path' % obj.name)
+    out.shape = SHAPE[obj.shape_kind]
+    out.interact = INTERACT[obj.interact_kind]
+    flags = 0
+    if p['check_size']:
+        flags |= F_CHECK_SIZE
+    if p['check_aperture']:
+        flags |= F_CHECK_APERTURE
+    half = [0.0, 0.0, 0.0]
+    for k, (key, flag) in enumerate((('xsize', F_HAS_XSIZE), ('ysize', F_HAS_YSIZE), ('zsize', F_HAS_ZSIZE))):
+        if p[key] is not None:
+            flags |= flag
+            half[k] = p[key] / 2
+    if p['trace_local']:
+        flags |= F_TRACE_LOCAL
+    _vec(out.origin, obj.origin)
+    _vec(out.orientation, obj.orientation)
+    _vec(out.half_size, half)
+
+    out.radius = out.radius2 = 0.0
+    _vec(out.center, np.zeros(3))
+    out.torus_major = out.torus_minor = 0.0
+    out.torus_root = 0
+    if obj.shape_kind in ('sphere', 'cylinder'):
+        out.radius = float(p['radius'])
+        out.radius2 = float(p['radius'] ** 2)
+        _vec(out.center, p['center'])
+        if p['convex']:
+            flags |= F_CONVEX
+    elif obj.shape_kind == 'torus':
+        out.torus_major = float(p['torus_major'])
+        out.torus_minor = float(p['torus_minor'])
+        out.torus_root = int(p['root_idx'])
+        _vec(out.center, p['center'])
+
+    out.rocking_type = ROCKING_GAUSS
+    out.two_d = out.rocking_half_fwhm = out.rocking_2sigma2 = 0.0
+    out.reflectivity = 1.0
+    out.half_pi = float(np.pi / 2)
+    if obj.interact_kind == 'crystal':
+        # `check_bragg is False` is the reference's test (_InteractCrystal.py:120)
+        if p['check_bragg'] is not False:
+            flags |= F_CHECK_BRAGG
+            rt = p['rocking_type']
+            if 'step' in rt:
+                out.rocking_type = ROCKING_STEP
+                out.rocking_half_fwhm = float(p['rocking_fwhm'] / 2)
+            elif 'gauss' in rt:
+                out.rocking_type = ROCKING_GAUSS
+                sigma = p['rocking_fwhm'] / (2 * np.sqrt(2 * np.log(2)))
+                out.rocking_2sigma2 = float(2 * sigma ** 2)
+            elif 'file' in rt:
+                # the reference's reader raises NameError (xicsrt_bragg.py:40,85,87)
+                raise NameError("name 'm_log' is not defined")
+            else:
+                raise Exception('Rocking curve type not understood: {}'.format(rt))
+            out.two_d = float(2 * p['crystal_spacing'])
+            out.reflectivity = float(p['reflectivity'])
+
+    aps = _aperture_list(p['aperture'])
+    if len(aps) > XRT_MAX_APERTURES:
+        raise SceneError('more than %d apertures on one optic' % XRT_MAX_APERTURES)
+    out.n_apertures = len(aps)
+    for k, ap in enumerate(aps):
+        a = out.apertures[k]
+        shape = (ap.get('shape') or 'none').lower()
+        logic = (ap.get('logic') or 'and').lower()
+        if shape not in AP_SHAPE:
+            raise Exception(f'Aperture shape: "{shape}" is not implemented.')
+        if logic not in AP_LOGIC:
+            raise Exception(f'Aperture logic "{logic}" is not known.')
+        a.shape, a.logic = AP_SHAPE[shape], AP_LOGIC[logic]
+        origin = ap.get('origin')
+        origin = np.array([0.0, 0.0]) if origin is None else np.asarray(origin, dtype=np.float64).ravel()
+        _vec(a.origin, origin[0:2])
+        size = np.zeros(2)
+        if 'size' in ap:
+            s = np.asarray(ap['size'], dtype=np.float64).ravel()
+            size[:min(2, len(s))] = s[:2]
+        _vec(a.size, size)
+        verts = np.zeros(6)
+        if shape == 'triangle':
+            v = np.asarray(ap['vertices'], dtype=np.float64)
+            verts = np.concatenate([v[i, 0:2] + origin[0:2] for i in range(3)])
+        _vec(a.vertices, verts)
+
+    bins = 0
+    out.pixel_size = out.pixel_xoff = out.pixel_yoff = 0.0
+    out.pixel_nx = out.pixel_ny = 0
+    out.image_offset = image_offset
+    if p['enable_image']:
+        flags |= F_IMAGE
+        out.pixel_size = float(p['pixel_size'])
+        out.pixel_nx, out.pixel_ny = int(p['pixel_xsize']), int(p['pixel_ysize'])
+        out.pixel_xoff = float((p['pixel_xsize'] - 1) / 2)
+        out.pixel_yoff = float((p['pixel_ysize'] - 1) / 2)
+        bins = out.pixel_nx * out.pixel_ny
+    out.flags = flags
+    return bins
+
+
+class FlatScene:
+    """A Scene struct plus everything that must stay alive with it."""
+
+    def __init__(self, source_obj, optic_objs, names):
+        if len(optic_objs) > XRT_MAX_OPTICS:
+            raise SceneError('more than %d optics' % XRT_MAX_OPTICS)
+        self.struct = Scene()
+        self._keep = []
+        self.names = list(names)                    # source name then optic names
+        flatten_source(source_obj, self.struct.source, self._keep)
+        self.struct.n_optics = len(optic_objs)
+        offset = 0
+        self.image_slices = {}
+        for k, (name, obj) in enumerate(zip(self.names[1:], optic_objs)):
+            bins = flatten_optic(obj, self.struct.optics[k], offset)
+            if bins:
+                o = self.struct.optics[k]
+                self.image_slices[name] = (offset, o.pixel_nx, o.pixel_ny)
+            else:
+                self.image_slices[name] = None
+            offset += bins
+        self.struct.image_bins = offset
+
+    @property
+    def n_elements(self):
+        return self.struct.n_optics + 1
+
+    @property
+    def n_rays(self):
+        return int(self.struct.source.intensity)
+
+    @property
+    def image_bins(self):
+        return int(self.struct.image_bins)
+
+    def byref(self):
+        return C.byref(self.struct)

@@ -1,0 +1,113 @@
+"""
+Ray sources of the plug-in surface: class names, config keys and set-up rules
+of the reference; the per-ray sampling itself runs on the device.
+
+  XicsrtSourceGeneric   cuboid/gaussian volume, cone about the zaxis
+                        (xicsrt/sources/_XicsrtSourceGeneric.py:20-396)
+  XicsrtSourceDirected  cone about an explicit `direction`
+                        (xicsrt/sources/_XicsrtSourceDirected.py:16-50)
+  XicsrtSourceFocused   cone aimed at `target` from every origin
+                        (xicsrt/sources/_XicsrtSourceFocused.py:16-44)
+"""
+import numpy as np
+
+from ..objects import GeometryObject
+
+
+class XicsrtSourceGeneric(GeometryObject):
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.filter_objects = []
+
+    def default_config(self):
+        """
+        xsize, ysize, zsize : full widths of the emitting volume (fwhm if gaussian)
+        spatial_dist        : 'uniform' | 'gaussian'
+        angular_dist        : 'isotropic' | 'isotropic_xy' | 'flat' | 'flat_xy'
+        spread              : half-angle(s) of the emission cone [rad]
+        intensity           : rays per iteration
+        use_poisson         : draw the ray count from Poisson(intensity)
+        wavelength_dist     : 'voigt' | 'uniform' | 'monochrome'
+        wavelength, wavelength_range, linewidth, mass_number, temperature, velocity
+        filters             : names of ray filters
+        """
+        config = super().default_config()
+        config['xsize'] = 0.0
+        config['ysize'] = 0.0
+        config['zsize'] = 0.0
+        config['intensity'] = 0.0
+        config['use_poisson'] = False
+        config['spatial_dist'] = 'uniform'
+        config['angular_dist'] = 'isotropic'
+        config['spread'] = np.pi
+        config['wavelength_dist'] = 'voigt'
+        config['wavelength'] = 1.0
+        config['mass_number'] = 1.0
+        config['linewidth'] = 0.0
+        config['temperature'] = 0.0
+        config['velocity'] = np.array([0.0, 0.0, 0.0])
+        config['wavelength_range'] = np.array([0.0, 0.0])
+        config['filters'] = []
+        return config
+
+    def initialize(self):
+        super().initialize()
+        if self.param['use_poisson']:
+            # Consumes the legacy global stream exactly as the reference does
+            # (_XicsrtSourceGeneric.py:191-192); the device run loop handles
+            # this itself for seeded runs, see xicsrt_amd/xicsrt_raytrace.py.
+            self.param['intensity'] = np.random.poisson(self.param['intensity'])
+        elif self.param['intensity'] < 1:
+            raise ValueError('intensity of less than one encountered. Turn on poisson statistics.')
+        self.param['intensity'] = int(self.param['intensity'])
+
+    # which vector the emission cone is built around (see scene.flatten_source)
+    cone_axis_rule = 'zaxis'
+
+    def cone_axis(self):
+        return self.param['zaxis']
+
+    def generate_rays(self):
+        """
+        Rays of one iteration drawn from the *current global np.random state*,
+        as the reference's method does; runs on the device.
+        """
+        from .. import xicsrt_raytrace as _rt
+        return _rt.generate_rays_from_global_state(self)
+
+
+class XicsrtSourceDirected(XicsrtSourceGeneric):
+
+    cone_axis_rule = 'direction'
+
+    def default_config(self):
+        """direction : axis of the emission cone (defaults to the zaxis)."""
+        config = super().default_config()
+        config['direction'] = None
+        return config
+
+    def initialize(self):
+        super().initialize()
+        if self.param['direction'] is None:
+            self.param['direction'] = self.param['zaxis']
+
+    def cone_axis(self):
+        return self.param['direction']
+
+
+class XicsrtSourceFocused(XicsrtSourceGeneric):
+
+    cone_axis_rule = 'target'
+
+    def default_config(self):
+        """target : point every emission cone is aimed at."""
+        config = super().default_config()
+        config['target'] = None
+        return config
+
+    def cone_axis(self):
+        return self.param['target']
+
+
+BUILTIN = {cls.__name__: cls for cls in (XicsrtSourceGeneric, XicsrtSourceDirected, XicsrtSourceFocused)}

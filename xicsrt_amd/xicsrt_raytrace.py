@@ -1,0 +1,580 @@
+"""
+Run driver: `raytrace(config)` and friends, on the device.
+
+Mirrors the reference's driver semantics (behaviour, not code):
+
+  raytrace            run loop, per-run seed, merge, reset of per-run options
+                      (xicsrt/xicsrt_raytrace.py:28-84)
+  raytrace_single     one run = one MT19937 stream; filters -> sources -> optics
+                      are built in that order; iteration loop
+                      (xicsrt/xicsrt_raytrace.py:87-175)
+  _sort_raytrace      found / lost split, shuffled truncation of lost rays
+                      (xicsrt/xicsrt_raytrace.py:229-278)
+  combine_raytrace    sums of meta and images, concatenated histories
+                      (xicsrt/xicsrt_raytrace.py:281-393)
+  raytrace_mp         same result as raytrace; the `multiprocessing.Pool` over
+                      runs (xicsrt/xicsrt_multiprocessing.py:12-81) is replaced by
+                      runs in flight on the GPU, and by one process per GPU
+                      (torch.distributed over RCCL) with a single all-reduce of
+                      the integer histogram and counters.
+
+Seed schedule: run i uses seed + i(i+1)/2 (cumulative `random_seed += ii`,
+xicsrt_raytrace.py:60-63).
+
+All per-ray arithmetic is done by libxicsrt_hip.so through the C ABI
+(include/xicsrt_hip.h).  PyTorch only supplies device buffers, the stream and
+the process group.
+"""
+import copy
+import ctypes as C
+import importlib.util
+import glob
+import logging
+import os
+
+import numpy as np
+
+from . import config as xconfig
+from . import scene as xscene
+from .objects import RayArray
+from . import sources as _sources
+from . import optics as _optics
+
+m_log = logging.getLogger('xicsrt')
+
+_RAY_KEYS = ('origin', 'direction', 'mask', 'wavelength')
+
+
+# ---------------------------------------------------------------------------
+# element construction (Dispatcher.instantiate/setup/check_param/initialize,
+# xicsrt/objects/_Dispatcher.py:44-140)
+# ---------------------------------------------------------------------------
+
+def _builtin_registry(section):
+    if section == 'sources':
+        return _sources.BUILTIN
+    if section == 'optics':
+        return _optics.BUILTIN
+    return {}
+
+
+def find_class(class_name, section, pathlist):
+    """
+    Resolve `class_name`.  Built-in names map to this package's classes.  A file
+    `_<class_name>.py` on the user `pathlist` is loaded the way the reference
+    loads plug-ins (_Dispatcher.py:63-113); it is accepted when the class is a
+    re-parametrisation of built-in shapes/interactions (the device cannot run
+    arbitrary NumPy methods), otherwise NotImplementedError.
+    """
+    for path in pathlist or []:
+        for filepath in glob.glob(os.path.join(path, '_%s.py' % class_name)):
+            spec = importlib.util.spec_from_file_location(class_name, filepath)
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            cls = getattr(mod, class_name)
+            base = _sources.XicsrtSourceGeneric if section == 'sources' else _optics.TraceObject
+            if not issubclass(cls, base):
+                raise NotImplementedError(
+                    'User plug-in %s (%s) is not built from xicsrt_amd element classes; arbitrary NumPy '
+                    'plug-ins cannot run on the device path and there is no CPU fallback.' % (class_name, filepath))
+            return cls
+    registry = _builtin_registry(section)
+    if class_name in registry:
+        return registry[class_name]
+    if class_name in getattr(_optics, 'NOT_IMPLEMENTED', ()):
+        raise NotImplementedError('%s is not implemented on the device path yet.' % class_name)
+    raise Exception('Could not find {} in available objects.'.format(class_name))
+
+
+class Elements:
+    """The initialised objects of one run: one source and the optics in config order."""
+
+    def __init__(self, config):
+        general = config['general']
+        strict = general['strict_config_check']
+        pathlist = list(general.get('pathlist', []) or [])
+        if config.get('filters'):
+            raise NotImplementedError('ray/bundle filters are not implemented on the device path yet.')
+        sources = config['sources']
+        if len(sources) == 0:
+            raise Exception('No ray sources defined.')
+        if len(sources) != 1:
+            raise NotImplementedError('Multiple ray sources are not currently supported.')
+        self.objects = {}
+        self.source_name = list(sources.keys())[0]
+        built = {}
+        for section in ('sources', 'optics'):
+            objs = {}
+            for key, sub in config[section].items():
+                cls = find_class(sub['class_name'], section, pathlist)
+                objs[key] = cls(sub, initialize=False, strict=strict)
+            for method in ('setup', 'check_param', 'initialize'):
+                for obj in objs.values():
+                    getattr(obj, method)()
+            built[section] = objs
+        self.source = built['sources'][self.source_name]
+        self.optic_names = list(built['optics'].keys())
+        self.optics = [built['optics'][k] for k in self.optic_names]
+        self.names = [self.source_name] + self.optic_names
+
+    def get_config(self, section):
+        if section == 'sources':
+            return {self.source_name: self.source.get_config()}
+        return {k: o.get_config() for k, o in zip(self.optic_names, self.optics)}
+
+    def flatten(self):
+        return xscene.FlatScene(self.source, self.optics, self.names)
+
+
+def run_seeds(random_seed, num_runs):
+    """Per-run seeds: cumulative increment, i.e. seed + i(i+1)/2 (xicsrt_raytrace.py:60-63)."""
+    if random_seed is None:
+        return [int.from_bytes(os.urandom(4), 'little') for _ in range(num_runs)]
+    seeds = []
+    s = random_seed
+    for ii in range(num_runs):
+        s += ii
+        seeds.append(int(s))
+    return seeds
+
+
+def _check_seed(seed):
+    if seed < 0 or seed > 2 ** 32 - 1:
+        raise ValueError('Seed must be between 0 and 2**32 - 1')
+    return seed
+
+
+def check_config(config):
+    """Output directory must exist when anything is to be saved (xicsrt_raytrace.py:396-411)."""
+    do_save = any(config['general'][key] for key in config['general'] if 'save' in key)
+    if do_save:
+        path = config['general']['output_path']
+        if path is None or not os.path.exists(path):
+            if not config['general']['make_directories']:
+                raise Exception('Output directory does not exist. Create directory or set make_directories to True.')
+
+
+# ---------------------------------------------------------------------------
+# device plumbing
+# ---------------------------------------------------------------------------
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError('xicsrt_amd needs a HIP device (torch.cuda.is_available() is False); '
+                           'there is no CPU fallback.')
+    return torch
+
+
+def _dist():
+    """(rank, world) of the default process group, (0, 1) when not distributed."""
+    try:
+        import torch.distributed as dist
+    except Exception:
+        return None, 0, 1
+    if dist.is_available() and dist.is_initialized():
+        return dist, dist.get_rank(), dist.get_world_size()
+    return None, 0, 1
+
+
+def shard_runs(num_runs, rank, world):
+    """Run indices of `rank`: i = rank, rank + world, ... (runs are independent units)."""
+    return list(range(rank, num_runs, world))
+
+
+def rng_state_from_seed(seed):
+    """init_genrand state as np.random.seed(seed) leaves it (key[624], pos=624, no cached gauss)."""
+    st = np.random.RandomState(_check_seed(int(seed))).get_state()
+    return st[1].astype(np.uint32), int(st[2]), int(st[3]), float(st[4])
+
+
+class DeviceTrace:
+    """Owns the device buffers of one flattened scene and issues the C ABI calls."""
+
+    def __init__(self, flat):
+        from . import capi
+        self.torch = _torch()
+        self.lib = capi.lib()
+        self.capi = capi
+        self.flat = flat
+        capi.check(self.lib.xrt_scene_check(flat.byref()), 'xrt_scene_check')
+        t = self.torch
+        self.dev = t.device('cuda', t.cuda.current_device())
+        self.num_out = t.zeros(flat.n_elements, dtype=t.int64, device=self.dev)
+        self.images = t.zeros(max(flat.image_bins, 1), dtype=t.int64, device=self.dev)
+        self._ws = None
+
+    def _workspace(self, n_runs):
+        need = int(self.lib.xrt_workspace_bytes(self.flat.byref(), n_runs))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = self.torch.empty(max(need, 16), dtype=self.torch.uint8, device=self.dev)
+        return self._ws, need
+
+    def trace(self, seeds, n_iter, keep_images=True):
+        """Launch all runs (asynchronous); results accumulate into num_out / images."""
+        if len(seeds) == 0:
+            return
+        seeds_arr = (C.c_uint32 * len(seeds))(*[_check_seed(int(s)) for s in seeds])
+        ws, need = self._workspace(len(seeds))
+        stream = self.torch.cuda.current_stream().cuda_stream
+        st = self.lib.xrt_trace(self.flat.byref(), seeds_arr, len(seeds), int(n_iter),
+                                self.num_out.data_ptr(),
+                                self.images.data_ptr() if keep_images else None,
+                                ws.data_ptr(), need, stream)
+        self.capi.check(st, 'xrt_trace')
+
+    def trace_history(self, state, keep_images=True):
+        """
+        One iteration from an explicit MT19937 state (key, pos, has_gauss, gauss).
+        Returns (rays[n_el, 8, N] float64, mask[n_el, N] bool, state_out) on the host.
+        """
+        t = self.torch
+        n, ne = self.flat.n_rays, self.flat.n_elements
+        rays = t.full((ne, xscene.XRT_HIST_COMPONENTS, max(n, 1)), float('nan'), dtype=t.float64, device=self.dev)
+        mask = t.zeros((ne, max(n, 1)), dtype=t.uint8, device=self.dev)
+        st_in = xscene.RngState()
+        key, pos, has_gauss, gauss = state
+        C.memmove(st_in.key, np.ascontiguousarray(key, dtype=np.uint32).ctypes.data, 624 * 4)
+        st_in.pos, st_in.has_gauss, st_in.gauss = int(pos), int(has_gauss), float(gauss)
+        st_out = t.zeros(C.sizeof(xscene.RngState), dtype=t.uint8, device=self.dev)
+        ws, need = self._workspace(1)
+        stream = t.cuda.current_stream().cuda_stream
+        status = self.lib.xrt_trace_history(self.flat.byref(), C.byref(st_in),
+                                            self.num_out.data_ptr(),
+                                            self.images.data_ptr() if keep_images else None,
+                                            rays.data_ptr(), mask.data_ptr(), st_out.data_ptr(),
+                                            ws.data_ptr(), need, stream)
+        self.capi.check(status, 'xrt_trace_history')
+        t.cuda.current_stream().synchronize()
+        out = xscene.RngState.from_buffer_copy(st_out.cpu().numpy().tobytes())
+        state_out = (np.ctypeslib.as_array(out.key).copy(), int(out.pos), int(out.has_gauss), float(out.gauss))
+        return rays.cpu().numpy()[:, :, :n], mask.cpu().numpy()[:, :n].astype(bool), state_out
+
+    def results(self):
+        """Host copies (synchronises the stream): num_out list, {optic: image or None}."""
+        self.torch.cuda.current_stream().synchronize()
+        return self.unpack(self.num_out.cpu().numpy(), self.images.cpu().numpy())
+
+    def unpack(self, num_out, images):
+        meta = {}
+        for k, name in enumerate(self.flat.names):
+            meta[name] = {'num_out': np.int64(num_out[k])}
+        image = {}
+        for name in self.flat.names[1:]:
+            sl = self.flat.image_slices[name]
+            if sl is None:
+                image[name] = None
+            else:
+                off, nx, ny = sl
+                image[name] = images[off:off + nx * ny].reshape(nx, ny).astype(np.float64)
+        return meta, image
+
+
+# ---------------------------------------------------------------------------
+# result dictionaries
+# ---------------------------------------------------------------------------
+
+def _empty_output(config):
+    return {'config': config,
+            'total': {'meta': {}, 'image': {}},
+            'found': {'meta': {}, 'history': {}},
+            'lost': {'meta': {}, 'history': {}}}
+
+
+def _history_from_device(names, rays, mask):
+    """
+    Per-element ray dictionaries in original ray order from the device snapshot.
+    Rays that died at an element carry the intersection point they died at
+    (or NaN), later elements see NaN origins and the unchanged direction, as
+    the reference's masked NumPy updates leave them (optics/_ShapeObject.py:76-79,
+    _InteractObject.py:36-39).
+    """
+    history = {}
+    n = mask.shape[1]
+    prev_dir = None
+    prev_wl = None
+    prev_mask = None
+    for e, name in enumerate(names):
+        origin = np.ascontiguousarray(rays[e, 0:3, :].T)
+        direction = np.ascontiguousarray(rays[e, 3:6, :].T)
+        wavelength = rays[e, 6, :].copy()
+        m = mask[e].copy()
+        if e > 0:
+            dead_before = ~prev_mask
+            origin[dead_before] = np.nan
+            direction[dead_before] = prev_dir[dead_before]
+            wavelength[dead_before] = prev_wl[dead_before]
+        history[name] = RayArray({'origin': origin, 'direction': direction,
+                                  'wavelength': wavelength, 'mask': m})
+        if e == 0:
+            history[name]['weight'] = rays[e, 7, :].copy()
+        prev_dir, prev_wl, prev_mask = direction, wavelength, m
+    assert n == len(prev_mask)
+    return history
+
+
+def _sort_history(history, rng, max_lost):
+    """found/lost split with the reference's shuffled truncation (xicsrt_raytrace.py:253-274)."""
+    found, lost = {}, {}
+    keys = list(history.keys())
+    last = history[keys[-1]]['mask']
+    w_found = np.flatnonzero(last)
+    w_lost = np.flatnonzero(np.invert(last))
+    max_lost = min(max_lost, len(w_lost))
+    index_lost = np.arange(len(w_lost))
+    rng.shuffle(index_lost)
+    w_lost = w_lost[index_lost[:max_lost]]
+    for key in keys:
+        found[key] = {k: v[w_found] for k, v in history[key].items()}
+        lost[key] = {k: v[w_lost] for k, v in history[key].items()}
+    return found, lost
+
+
+def combine_raytrace(input_list, keep_images=True, components=None):
+    """Combine result dictionaries: sum meta and images, concatenate histories."""
+    output = _empty_output(input_list[0]['config'])
+    num = len(input_list)
+    if components is None:
+        key_opt_list = list(input_list[0]['total']['meta'].keys())
+    else:
+        key_opt_list = components
+    key_opt_last = key_opt_list[-1]
+
+    for key_opt in key_opt_list:
+        output['total']['meta'][key_opt] = {}
+        for key_meta in input_list[0]['total']['meta'][key_opt]:
+            total = 0
+            for entry in input_list:
+                total += entry['total']['meta'][key_opt][key_meta]
+            output['total']['meta'][key_opt][key_meta] = total
+
+    if keep_images:
+        for key_opt in key_opt_list:
+            if key_opt not in input_list[0]['total']['image']:
+                continue
+            first = input_list[0]['total']['image'][key_opt]
+            if first is None:
+                output['total']['image'][key_opt] = None
+                continue
+            if all(entry['total']['image'][key_opt].shape == first.shape for entry in input_list):
+                acc = np.zeros(first.shape)
+                for entry in input_list:
+                    acc += entry['total']['image'][key_opt]
+                output['total']['image'][key_opt] = acc
+            else:
+                m_log.warning('Image dimensions do not match. Cannot combine images.')
+                output['total']['image'][key_opt] = None
+
+    if len(input_list[0]['found']['history']) > 0:
+        for group in ('found', 'lost'):
+            total = sum(len(entry[group]['history'][key_opt_last]['mask']) for entry in input_list)
+            for key_opt in key_opt_list:
+                rays = RayArray()
+                rays.zeros(total)
+                index = 0
+                for entry in input_list:
+                    h = entry[group]['history'][key_opt]
+                    cnt = len(entry[group]['history'][key_opt_last]['mask'])
+                    for key_ray in _RAY_KEYS:
+                        rays[key_ray][index:index + cnt] = h[key_ray][:]
+                    index += cnt
+                output[group]['history'][key_opt] = rays
+    assert num == len(input_list)
+    return output
+
+
+def print_raytrace(results):
+    keys = list(results['total']['meta'].keys())
+    num_source = results['total']['meta'][keys[0]]['num_out']
+    num_detector = results['total']['meta'][keys[-1]]['num_out']
+    print('')
+    print('Rays Generated: {:6.3e}'.format(num_source))
+    print('Rays Detected:  {:6.3e}'.format(num_detector))
+    print('Efficiency:     {:6.3e} ± {:3.1e} ({:7.5f}%)'.format(
+        num_detector / num_source, np.sqrt(num_detector) / num_source, num_detector / num_source * 100))
+    print('')
+
+
+# ---------------------------------------------------------------------------
+# public drivers
+# ---------------------------------------------------------------------------
+
+def _prepare(config):
+    config = xconfig.get_config(config)
+    check_config(config)
+    elements = Elements(config)
+    config['sources'] = elements.get_config('sources')
+    config['optics'] = elements.get_config('optics')
+    return config, elements
+
+
+def _advance(rng, state_out):
+    """Bring a numpy RandomState to the MT state the device reported."""
+    key, pos, has_gauss, gauss = state_out
+    rng.set_state(('MT19937', key, pos, has_gauss, gauss))
+
+
+def _run_with_history(config, elements, device, seed, max_lost_iter):
+    """One run with keep_history: iterations are issued one by one so that the lost-ray shuffle
+    (xicsrt_raytrace.py:265) consumes the run's stream between them exactly as in the reference."""
+    general = config['general']
+    rng = np.random.RandomState(_check_seed(int(seed)))
+    outputs = []
+    for _ in range(general['number_of_iter']):
+        st = rng.get_state()
+        rays, mask, state_out = device.trace_history((st[1], st[2], st[3], st[4]), general['keep_images'])
+        _advance(rng, state_out)
+        history = _history_from_device(elements.names, rays, mask)
+        found, lost = _sort_history(history, rng, max_lost_iter)
+        single = _empty_output(config)
+        # totals are accumulated on the device and filled in by the caller
+        single['total']['meta'] = {name: {'num_out': 0} for name in elements.names}
+        single['found']['history'] = found
+        single['lost']['history'] = lost
+        outputs.append(single)
+    return combine_raytrace(outputs)
+
+
+def _max_lost_iter(general, internal):
+    num_iter = general['number_of_iter']
+    max_lost = int(general['history_max_lost'] / num_iter)
+    if internal:
+        max_lost = max_lost // general['number_of_runs']
+    return max(int(max_lost), 1)
+
+
+def _raytrace_runs(config, run_indices, seeds, internal):
+    """Trace the given runs on this process' device; returns one combined result dict."""
+    config, elements = _prepare(config)
+    general = config['general']
+    flat = elements.flatten()
+    device = DeviceTrace(flat)
+    my_seeds = [seeds[i] for i in run_indices]
+    if general['keep_history']:
+        max_lost = _max_lost_iter(general, internal)
+        outputs = [_run_with_history(config, elements, device, s, max_lost) for s in my_seeds]
+        if not outputs:
+            return None, device, config
+        return combine_raytrace(outputs), device, config
+    device.trace(my_seeds, general['number_of_iter'], general['keep_images'])
+    return None, device, config
+
+
+def _finish(output, config_user_general):
+    general = output['config']['general']
+    if general['save_config'] or general['save_images'] or general['save_results']:
+        raise NotImplementedError('save_config/save_images/save_results are outside the device path '
+                                  '(reference xicsrt_io); save the returned dictionary instead.')
+    if general['print_results']:
+        print_raytrace(output)
+    return output
+
+
+def raytrace(config):
+    """
+    Perform `number_of_runs` ray-tracing runs of `number_of_iter` iterations each
+    and return the combined results dictionary.
+
+    When a torch.distributed process group is initialised (one process per
+    GPU) the runs are sharded over the ranks and the integer histogram and
+    counters are summed with one all-reduce (RCCL); every rank returns the
+    full result (histories, if kept, are those of the local runs).
+    """
+    config_in = xconfig.get_config(config)
+    general = config_in['general']
+    num_runs = general['number_of_runs']
+    seeds = run_seeds(general['random_seed'], num_runs)
+    dist, rank, world = _dist()
+    indices = shard_runs(num_runs, rank, world)
+
+    hist_output, device, cfg = _raytrace_runs(copy.deepcopy(config_in), indices, seeds, internal=True)
+
+    t = device.torch
+    if dist is not None and world > 1:
+        packed = t.cat([device.num_out, device.images])
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+        num_out = packed[:device.num_out.numel()].cpu().numpy()
+        images = packed[device.num_out.numel():].cpu().numpy()
+        meta, image = device.unpack(num_out, images)
+    else:
+        meta, image = device.results()
+
+    output = _empty_output(cfg)
+    if hist_output is not None:
+        output = hist_output
+        output['config'] = cfg
+    output['total']['meta'] = meta if general['keep_meta'] else {}
+    output['total']['image'] = image if general['keep_images'] else {}
+    output['config']['general']['output_run_suffix'] = general['output_run_suffix']
+    output['config']['general']['random_seed'] = general['random_seed']
+    return _finish(output, general)
+
+
+def raytrace_mp(config, processes=None):
+    """
+    Drop-in for xicsrt.raytrace_mp: identical results to `raytrace`.  `processes`
+    is accepted for compatibility; parallelism over runs happens on the GPU(s).
+    """
+    output = raytrace(config)
+    # reference quirk kept: raytrace_mp stores output_run_suffix into random_seed
+    # (xicsrt_multiprocessing.py:69)
+    output['config']['general']['random_seed'] = output['config']['general']['output_run_suffix']
+    return output
+
+
+def raytrace_single(config, _internal=False):
+    """One run (`general.random_seed` seeds it) of `number_of_iter` iterations."""
+    config_in = xconfig.get_config(config)
+    general = config_in['general']
+    seed = general['random_seed']
+    if seed is None:
+        seed = int.from_bytes(os.urandom(4), 'little')
+    saved_runs = general['number_of_runs']
+    hist_output, device, cfg = _raytrace_runs(copy.deepcopy(config_in), [0], [seed], internal=_internal)
+    meta, image = device.results()
+    output = hist_output if hist_output is not None else _empty_output(cfg)
+    output['config'] = cfg
+    output['total']['meta'] = meta if general['keep_meta'] else {}
+    output['total']['image'] = image if general['keep_images'] else {}
+    assert saved_runs == general['number_of_runs']
+    if _internal:
+        return output
+    return _finish(output, general)
+
+
+# ---------------------------------------------------------------------------
+# single-object API (plug-in surface): global np.random state in -> out
+# ---------------------------------------------------------------------------
+
+def _global_state():
+    st = np.random.get_state()
+    return st[1], st[2], st[3], st[4]
+
+
+def _set_global_state(state_out):
+    key, pos, has_gauss, gauss = state_out
+    np.random.set_state(('MT19937', key, pos, has_gauss, gauss))
+
+
+def generate_rays_from_global_state(source_obj):
+    """XicsrtSource*.generate_rays(): consumes the global legacy stream like the reference."""
+    flat = xscene.FlatScene(source_obj, [], ['source'])
+    device = DeviceTrace(flat)
+    rays, mask, state_out = device.trace_history(_global_state(), keep_images=False)
+    _set_global_state(state_out)
+    out = RayArray({'origin': np.ascontiguousarray(rays[0, 0:3, :].T),
+                    'direction': np.ascontiguousarray(rays[0, 3:6, :].T),
+                    'wavelength': rays[0, 6, :].copy(),
+                    'mask': mask[0].copy()})
+    out['weight'] = rays[0, 7, :].copy()
+    return out
+
+
+def trace_optic_object(optic_obj, rays):
+    raise NotImplementedError('tracing externally supplied ray arrays through a single optic '
+                              'is not implemented on the device path yet; use raytrace(config).')
+
+
+def image_of_optic_object(optic_obj, rays):
+    raise NotImplementedError('make_image on externally supplied ray arrays is not implemented '
+                              'on the device path yet; images are produced by raytrace(config).')
