@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define XRT_ABI_VERSION 3
+#define XRT_ABI_VERSION 4
 
 #define XRT_MAX_OPTICS     16
 #define XRT_MAX_APERTURES  8
@@ -105,7 +105,10 @@ typedef struct xrt_source {
     double  orientation[9];   /* rows xaxis, yaxis = zaxis x xaxis, zaxis (_GeometryObject.py:94) */
     double  size[3];          /* xsize, ysize, zsize (full widths)                         */
     double  spatial_A[9];     /* GAUSSIAN: sqrt(s)[:,None]*v of svd(cov), row-major (np.random.multivariate_normal) */
-    double  axis[3];         /* GENERIC: param zaxis; DIRECTED: param direction; FOCUSED: target */
+    double  axis[3];          /* GENERIC: param zaxis; DIRECTED: param direction; FOCUSED: target */
+    double  basis[9];         /* GENERIC/DIRECTED: rows o_2, o_1, normal of the emission frame,
+                               * computed by the host as _XicsrtSourceGeneric.py:262-285 does
+                               * (FOCUSED builds the frame per ray on the device)            */
     /* angular distribution constants, computed by the host as the reference does:
      *   ISOTROPIC    ang[0] = cos(spread)            (xicsrt_spread.py:102)
      *   FLAT         ang[0] = tan(spread)            (xicsrt_spread.py:235)

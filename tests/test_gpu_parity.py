@@ -1,0 +1,126 @@
+"""
+GPU parity tests proper (-m gpu): the HIP path, called through the C ABI,
+against (1) the golden vectors generated from the reference and (2) the CPU
+oracle on the same seeded inputs.  Integer results (masks, num_out, images)
+bit-exact; ray positions/directions/wavelengths within FLOAT_RTOL relative
+(north star: 1e-6; the only differences are last-ulp differences of the
+device's sin/cos/asin/acos/exp/atan).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+FLOAT_RTOL = 1e-12
+
+# features not on the device path yet (they must fail loudly, see test_host.py)
+NOT_ON_DEVICE = ('D_ToroidalCrystal', 'E_mesh', 'F_plasma', 'P_local', 'S_gaussian_spatial',
+                 'G_isotropic_xy', 'W_normal', 'W_doppler', 'Q_four')
+
+
+def _cases(kind):
+    return [n for n in helpers.golden_names(kind) if not n.startswith(NOT_ON_DEVICE)]
+
+
+@pytest.fixture(scope='module')
+def devlib():
+    from xicsrt_amd import capi
+    L = capi.lib()
+    n = C.c_int(0)
+    assert L.xrt_device_count(C.byref(n)) == 0 and n.value >= 1, L.xrt_last_error()
+    return L
+
+
+def _device_history(flat, seed):
+    from xicsrt_amd import xicsrt_raytrace as xrt
+    dev = xrt.DeviceTrace(flat)
+    rays, mask, st_out = dev.trace_history(xrt.rng_state_from_seed(seed))
+    meta, image = dev.results()
+    return dev, rays, mask, st_out, meta, image
+
+
+@pytest.mark.parametrize('name', _cases('trace'))
+def test_history_matches_reference_and_oracle(name, devlib):
+    cfg, gold = helpers.load_golden(name)
+    config, elements, flat = helpers.build(cfg)
+    seed = config['general']['random_seed']
+    dev, rays, mask, st_out, meta, image = _device_history(flat, seed)
+    # golden (reference) ------------------------------------------------
+    for nm in flat.names:
+        assert int(meta[nm]['num_out']) == int(gold['num_out/' + nm]), nm
+    for nm in flat.names[1:]:
+        if image[nm] is not None:
+            assert np.array_equal(image[nm].astype(np.int64), gold['image/' + nm]), 'image ' + nm
+    helpers.assert_history_matches_golden(flat, rays, mask, gold, rtol=FLOAT_RTOL)
+    rs = np.random.RandomState(0)
+    rs.set_state(('MT19937',) + tuple(st_out))
+    assert rs.random_sample() == float(gold['next_double'])
+    # oracle ---------------------------------------------------------------
+    o_num, o_img, o_rays, o_mask, o_st = helpers.oracle_history(flat, helpers.seed_state(seed))
+    assert np.array_equal(o_mask, mask)
+    both = ~np.isnan(o_rays)
+    assert np.array_equal(np.isnan(o_rays), np.isnan(rays))
+    err = np.max(np.abs(o_rays[both] - rays[both])) if both.any() else 0.0
+    assert err <= FLOAT_RTOL * max(1.0, float(np.max(np.abs(o_rays[both])))) if both.any() else True
+
+
+@pytest.mark.parametrize('name', _cases('counts'))
+def test_counts_match_reference_and_oracle(name, devlib):
+    from xicsrt_amd import xicsrt_raytrace as xrt
+    cfg, gold = helpers.load_golden(name)
+    config, elements, flat = helpers.build(cfg)
+    g = config['general']
+    seeds = xrt.run_seeds(g['random_seed'], g['number_of_runs'])
+    dev = xrt.DeviceTrace(flat)
+    dev.trace(seeds, g['number_of_iter'])
+    meta, image = dev.results()
+    o_num, o_img = helpers.oracle_counts(flat, seeds, g['number_of_iter'], threads=4)
+    o_images = helpers.split_images(flat, o_img)
+    for k, nm in enumerate(flat.names):
+        assert int(meta[nm]['num_out']) == int(gold['num_out/' + nm]), nm
+        assert int(meta[nm]['num_out']) == int(o_num[k]), nm
+    for nm in flat.names[1:]:
+        if image[nm] is not None:
+            assert np.array_equal(image[nm].astype(np.int64), gold['image/' + nm]), 'image ' + nm
+            assert np.array_equal(image[nm].astype(np.int64), o_images[nm]), 'image ' + nm
+
+
+def test_raytrace_entry_point_runs_config_dict(devlib):
+    """xicsrt.raytrace(config) drop-in: result schema and totals (xicsrt_raytrace.py:28, :239-251)."""
+    import xicsrt_amd as xicsrt
+    cfg, gold = helpers.load_golden('C_sphere_runs')
+    cfg['general']['print_results'] = False
+    res = xicsrt.raytrace(cfg)
+    assert set(res.keys()) == {'config', 'total', 'found', 'lost'}
+    assert list(res['total']['meta'].keys()) == ['source', 'crystal', 'detector']
+    for nm in ('source', 'crystal', 'detector'):
+        assert int(res['total']['meta'][nm]['num_out']) == int(gold['num_out/' + nm])
+    assert res['total']['image']['detector'].dtype == np.float64
+    assert np.array_equal(res['total']['image']['detector'].astype(np.int64), gold['image/detector'])
+    assert res['found']['history'] == {} and res['lost']['history'] == {}
+
+
+def test_run_partition_invariance(devlib):
+    """Any partition of the runs over ranks gives the same sums."""
+    from xicsrt_amd import xicsrt_raytrace as xrt
+    cfg, gold = helpers.load_golden('C_sphere_runs')
+    config, elements, flat = helpers.build(cfg)
+    seeds = xrt.run_seeds(config['general']['random_seed'], 4)
+    total = None
+    for world in (1, 2, 4):
+        acc_n = np.zeros(flat.n_elements, dtype=np.int64)
+        acc_i = np.zeros(max(flat.image_bins, 1), dtype=np.int64)
+        for rank in range(world):
+            dev = xrt.DeviceTrace(flat)
+            dev.trace([seeds[i] for i in xrt.shard_runs(4, rank, world)], 1)
+            dev.torch.cuda.synchronize()
+            acc_n += dev.num_out.cpu().numpy()
+            acc_i += dev.images.cpu().numpy()
+        if total is None:
+            total = (acc_n, acc_i)
+        assert np.array_equal(total[0], acc_n) and np.array_equal(total[1], acc_i)
+    assert int(total[0][2]) == int(gold['num_out/detector'])

@@ -1,0 +1,13 @@
+#!/bin/bash
+# Builds libxicsrt_hip.so for gfx950 (MI355X) in-tree.  hipcc cross-compiles
+# without a GPU.  -ffp-contract=off: the reference (NumPy) evaluates a*b+c with
+# two roundings; fused multiply-adds appear only where written explicitly.
+set -e
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+$HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared \
+    -ffp-contract=off -fno-fast-math \
+    -Wall -Wno-unused-function \
+    ${XRT_EXTRA_FLAGS} \
+    -o libxicsrt_hip.so xrt_kernels.hip
+echo "built $(pwd)/libxicsrt_hip.so"

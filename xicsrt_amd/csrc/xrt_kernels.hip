@@ -1,0 +1,994 @@
+// xrt_kernels.hip -- photon propagation for gfx950 (MI355X) and the C ABI of
+// include/xicsrt_hip.h.
+//
+// One workgroup (256 threads, 4 waves) owns one *run* = one MT19937 stream
+// (reference: xicsrt_raytrace.raytrace_single, xicsrt/xicsrt_raytrace.py:87) and
+// walks the run's rays in tiles of 256 in original ray order.  Everything
+// between "draw the random numbers" and "increment the detector pixel" happens
+// in registers and LDS; HBM only sees the pixel/counter atomics (and the
+// optional history snapshot).
+//
+//   * The reference draws whole arrays per quantity from ONE stream
+//     (x, y, z offsets, cone cosine, cone azimuth, wavelength; then, per Bragg
+//     optic, one uniform per ray still alive, in ray order).  Array k therefore
+//     lives at stream offset 2*k*N words.  Each needed array gets its own
+//     MT19937 "head": a 1024-word ring in LDS holding a sliding window of the
+//     state sequence s[n] = f(s[n-624], s[n-623], s[n-227]); 227 words are
+//     independent at a time, so a head advances by 512 words (256 doubles) in
+//     three barrier-separated phases.  Heads are positioned by walking the
+//     stream forward once per iteration (no tempering needed on the way).
+//   * The per-ray Bragg uniform is indexed by the ordered live rank, obtained
+//     from wave64 ballots + a 4-entry LDS scan; the same rank drives a stable
+//     compaction of the live rays into an LDS tile so that the next stage runs
+//     on dense lanes.
+//   * Arithmetic is IEEE binary64 in the reference's evaluation order
+//     (-ffp-contract=off; explicit fma() only where the reference's BLAS call
+//     fuses), so masks, counts and images are bit-identical to the CPU result.
+//
+// Reference functions restated per stage are cited at each device function.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <stdio.h>
+#include <math.h>
+
+#include "../../include/xicsrt_hip.h"
+
+#define XRT_DEV_MAX_OPTICS 8
+#define XRT_TILE     256
+#define XRT_RING     1024u
+#define XRT_RMASK    1023u
+#define XRT_MAX_HEADS 7         // 6 source arrays + the stream head
+#define XRT_TILE_COMP 10        // x,y,z, dx,dy,dz, wavelength, nx,ny,nz
+
+// --------------------------------------------------------------------------
+// kernel-argument scene (passed by value: uniform, read through scalar loads)
+// --------------------------------------------------------------------------
+
+struct KSource {
+    int32_t kind, angular_dist, wavelength_dist, has_velocity;
+    int64_t n_rays;
+    double  origin[3];
+    double  xaxis[3], yaxis[3], zaxis[3];
+    double  low[3], range[3];
+    double  axis[3];
+    double  basis[9];           // rows o_2, o_1, normal for GENERIC/DIRECTED
+    double  ang[5];
+    double  two_pi;
+    double  wavelength, wl_a, wl_b;
+    double  velocity[3];
+    double  light_speed;
+    const double* voigt_cdf;    // device
+    const double* voigt_x;      // device
+    int32_t voigt_n;
+    int32_t n_arrays;           // arrays of N doubles the source consumes (5 or 6)
+    uint32_t array_used;        // bit k: values of array k are needed
+};
+
+struct KOptic {
+    int32_t shape, interact, flags, rocking_type;
+    double  origin[3];
+    double  R[9];
+    double  half_size[3];
+    double  radius, radius2;
+    double  center[3];
+    double  two_d, reflectivity, half_fwhm, two_sigma2, half_pi;
+    double  pixel_size, pixel_xoff, pixel_yoff;
+    int32_t pixel_nx, pixel_ny;
+    int64_t image_offset;
+    const xrt_aperture_t* apertures;    // device
+    int32_t n_apertures;
+    int32_t pad;
+};
+
+struct KScene {
+    KSource src;
+    int32_t n_optics;
+    int32_t pad;
+    KOptic  opt[XRT_DEV_MAX_OPTICS];
+};
+
+struct KState {             // xrt_rng_state_t layout
+    uint32_t key[624];
+    int32_t  pos;
+    int32_t  has_gauss;
+    double   gauss;
+};
+
+// --------------------------------------------------------------------------
+// MT19937 (numpy legacy RandomState)
+// --------------------------------------------------------------------------
+
+__device__ __forceinline__ uint32_t mt_mix(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+    return c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y)
+{
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+// genrand_res53: (a*2^26 + b) / 2^53, exact in binary64
+__device__ __forceinline__ double mt_double(uint32_t w0, uint32_t w1)
+{
+    uint32_t a = mt_temper(w0) >> 5, b = mt_temper(w1) >> 6;
+    return ((double)a * 67108864.0 + (double)b) * (1.0 / 9007199254740992.0);
+}
+
+// Advance ring `r` (holding s[.. gen)) by `count` words, all threads of the
+// workgroup cooperating; at most 227 words are independent.  Ends with a barrier.
+__device__ __forceinline__ void ring_advance(uint32_t* r, uint64_t gen, uint32_t count, int tid)
+{
+    for (uint32_t done = 0; done < count; done += 227u) {
+        uint32_t chunk = count - done;
+        if (chunk > 227u) chunk = 227u;
+        if ((uint32_t)tid < chunk) {
+            uint32_t n = (uint32_t)gen + done + (uint32_t)tid;
+            r[n & XRT_RMASK] = mt_mix(r[(n - 624u) & XRT_RMASK], r[(n - 623u) & XRT_RMASK],
+                                      r[(n - 227u) & XRT_RMASK]);
+        }
+        __syncthreads();
+    }
+}
+
+// --------------------------------------------------------------------------
+// 3-vector helpers in NumPy's evaluation order (see oracle/xrt_oracle.c header)
+// --------------------------------------------------------------------------
+
+struct V3 { double x, y, z; };
+
+__device__ __forceinline__ double dot_e(const V3& a, const V3& b) { return (a.x * b.x + a.z * b.z) + a.y * b.y; }
+__device__ __forceinline__ double dot_n(const V3& a, const V3& b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ double dot_blas(const V3& a, const V3& b) { return fma(a.z, b.z, fma(a.x, b.x, a.y * b.y)); }
+__device__ __forceinline__ double norm3(const V3& a) { return sqrt(dot_n(a, a)); }
+__device__ __forceinline__ V3 cross3(const V3& a, const V3& b)
+{
+    V3 c;
+    c.x = a.y * b.z - a.z * b.y;
+    c.y = a.z * b.x - a.x * b.z;
+    c.z = a.x * b.y - a.y * b.x;
+    return c;
+}
+__device__ __forceinline__ V3 ld3(const double* p) { V3 v; v.x = p[0]; v.y = p[1]; v.z = p[2]; return v; }
+__device__ __forceinline__ V3 sub3(const V3& a, const V3& b) { V3 c; c.x = a.x - b.x; c.y = a.y - b.y; c.z = a.z - b.z; return c; }
+// GeometryObject.vector_to_local (xicsrt/objects/_GeometryObject.py:157-168)
+__device__ __forceinline__ V3 to_local(const double* R, const V3& v)
+{
+    V3 o;
+    o.x = dot_e(ld3(R + 0), v);
+    o.y = dot_e(ld3(R + 3), v);
+    o.z = dot_e(ld3(R + 6), v);
+    return o;
+}
+
+// np.interp (numpy/core/src/multiarray/compiled_base.c arr_interp)
+__device__ double np_interp(double x, const double* xp, const double* fp, int n)
+{
+    if (x != x) return x;
+    if (x < xp[0]) return fp[0];
+    if (x > xp[n - 1]) return fp[n - 1];
+    int lo = 0, hi = n - 1;
+    while (hi - lo > 1) {
+        int mid = (lo + hi) / 2;
+        if (x >= xp[mid]) lo = mid; else hi = mid;
+    }
+    int j = lo;
+    if (x == xp[n - 1]) return fp[n - 1];
+    if (xp[j] == x) return fp[j];
+    double slope = (fp[j + 1] - fp[j]) / (xp[j + 1] - xp[j]);
+    double r = slope * (x - xp[j]) + fp[j];
+    if (r != r) {
+        r = slope * (x - xp[j + 1]) + fp[j + 1];
+        if (r != r && fp[j] == fp[j + 1]) r = fp[j];
+    }
+    return r;
+}
+
+// --------------------------------------------------------------------------
+// source: XicsrtSourceGeneric.generate_rays (sources/_XicsrtSourceGeneric.py:198-227)
+// --------------------------------------------------------------------------
+
+struct Ray {
+    V3 o, d;
+    double wl;
+};
+
+// u[k] = the k-th array's double for this ray (0.0 for arrays whose value cannot matter)
+__device__ __forceinline__ void source_ray(const KSource& s, const double* u, Ray& ray)
+{
+    // generate_origin (:229-255): origin + x*xaxis + y*yaxis + z*zaxis, left to right
+    double xo = s.low[0] + s.range[0] * u[0];
+    double yo = s.low[1] + s.range[1] * u[1];
+    double zo = s.low[2] + s.range[2] * u[2];
+    ray.o.x = ((s.origin[0] + xo * s.xaxis[0]) + yo * s.yaxis[0]) + zo * s.zaxis[0];
+    ray.o.y = ((s.origin[1] + xo * s.xaxis[1]) + yo * s.yaxis[1]) + zo * s.zaxis[1];
+    ray.o.z = ((s.origin[2] + xo * s.xaxis[2]) + yo * s.yaxis[2]) + zo * s.zaxis[2];
+
+    // make_normal + basis (:262-285; Directed :46-50; Focused :40-44)
+    V3 n, o1, o2;
+    if (s.kind == XRT_SRC_FOCUSED) {
+        V3 a = sub3(ld3(s.axis), ray.o);
+        double m = norm3(a);
+        n.x = a.x / m; n.y = a.y / m; n.z = a.z / m;
+        V3 c1 = cross3(n, ld3(s.xaxis)), c2 = cross3(n, ld3(s.zaxis));
+        o1.x = c1.x + c2.x; o1.y = c1.y + c2.y; o1.z = c1.z + c2.z;
+        double m1 = norm3(o1);
+        o1.x /= m1; o1.y /= m1; o1.z /= m1;
+        o2 = cross3(n, o1);
+        double m2 = norm3(o2);
+        o2.x /= m2; o2.y /= m2; o2.z /= m2;
+    } else {
+        o2 = ld3(s.basis + 0); o1 = ld3(s.basis + 3); n = ld3(s.basis + 6);
+    }
+
+    // local direction about +z (tools/xicsrt_spread.py:80-294)
+    double l0, l1, l2;
+    if (s.angular_dist == XRT_ANG_ISOTROPIC) {
+        double z = s.ang[0] + (1.0 - s.ang[0]) * u[3];
+        double phi = 0.0 + (s.two_pi - 0.0) * u[4];
+        double st = sqrt(1.0 - z * z);
+        double sn, cs;
+        sincos(phi, &sn, &cs);
+        l0 = st * cs; l1 = st * sn; l2 = z;
+    } else if (s.angular_dist == XRT_ANG_FLAT) {
+        double r = sqrt(0.0 + (s.ang[0] - 0.0) * u[3]);
+        double a1 = 0.0 + (s.two_pi - 0.0) * u[4];
+        double a0 = atan(r);
+        double s1, c1, s0, c0;
+        sincos(a1, &s1, &c1);
+        sincos(a0, &s0, &c0);
+        l0 = c1 * s0; l1 = s1 * s0; l2 = c0;
+    } else {    // XRT_ANG_FLAT_XY
+        double x = s.ang[0] + (s.ang[1] - s.ang[0]) * u[3];
+        double y = s.ang[2] + (s.ang[3] - s.ang[2]) * u[4];
+        double a0 = atan(sqrt(x * x + y * y));
+        double a1 = atan2(y, x);
+        double s1, c1, s0, c0;
+        sincos(a1, &s1, &c1);
+        sincos(a0, &s0, &c0);
+        l0 = c1 * s0; l1 = s1 * s0; l2 = c0;
+    }
+    // einsum('ij,ijk->ik', dir_local, [o_2, o_1, normal]) (:287-292)
+    ray.d.x = (l0 * o2.x + l1 * o1.x) + l2 * n.x;
+    ray.d.y = (l0 * o2.y + l1 * o1.y) + l2 * n.y;
+    ray.d.z = (l0 * o2.z + l1 * o1.z) + l2 * n.z;
+
+    // generate_wavelength (:295-319)
+    double wl;
+    if (s.wavelength_dist == XRT_WL_UNIFORM) {
+        wl = s.wl_a + s.wl_b * u[5];
+    } else if (s.wavelength_dist == XRT_WL_VOIGT) {
+        double y = s.wl_a + s.wl_b * u[5];
+        wl = np_interp(y, s.voigt_cdf, s.voigt_x, s.voigt_n) + s.wavelength;
+    } else {
+        wl = 1.0 * s.wavelength;
+    }
+    if (s.has_velocity) {
+        double v = dot_e(ld3(s.velocity), ray.d);
+        wl *= 1.0 - (v / s.light_speed);
+    }
+    ray.wl = wl;
+}
+
+// --------------------------------------------------------------------------
+// optics
+// --------------------------------------------------------------------------
+
+// Shape*.intersect: distance, location, normal.  Returns false when the ray has
+// no intersection (mask &= ... in the reference).
+__device__ __forceinline__ bool intersect(const KOptic& op, const Ray& ray, V3& X, V3& nrm)
+{
+    double t;
+    if (op.shape == XRT_SHAPE_PLANE) {
+        // optics/_ShapePlane.py:32-62 (np.dot -> OpenBLAS dgemv fused order)
+        V3 za = ld3(op.R + 6);
+        V3 v = sub3(ld3(op.origin), ray.o);
+        t = dot_blas(v, za) / dot_blas(ray.d, za);
+        if (!(t >= 0.0)) return false;
+        nrm = za;
+        X.x = ray.o.x + ray.d.x * t; X.y = ray.o.y + ray.d.y * t; X.z = ray.o.z + ray.d.z * t;
+        return true;
+    } else if (op.shape == XRT_SHAPE_SPHERE) {
+        // optics/_ShapeSphere.py:52-106
+        V3 c = ld3(op.center);
+        V3 L = sub3(c, ray.o);
+        double t_ca = dot_e(L, ray.d);
+        double dd = sqrt(dot_e(L, L) - t_ca * t_ca);
+        if (!(dd <= op.radius)) return false;
+        double t_hc = sqrt(op.radius2 - dd * dd);
+        double t0 = t_ca - t_hc, t1 = t_ca + t_hc;
+        if (op.flags & XRT_F_CONVEX) t = (t0 < t1) ? t0 : t1;
+        else                         t = (t0 > t1) ? t0 : t1;
+        X.x = ray.o.x + ray.d.x * t; X.y = ray.o.y + ray.d.y * t; X.z = ray.o.z + ray.d.z * t;
+        V3 q = sub3(c, X);
+        double m = norm3(q);
+        nrm.x = q.x / m; nrm.y = q.y / m; nrm.z = q.z / m;
+        return true;
+    } else {
+        // optics/_ShapeCylinder.py:52-133
+        V3 pa = ld3(op.center), va = ld3(op.R + 0);
+        V3 dp = sub3(ray.o, pa);
+        double dDva = dot_e(ray.d, va), dpva = dot_e(dp, va);
+        V3 A1, B1;
+        A1.x = ray.d.x - dDva * va.x; A1.y = ray.d.y - dDva * va.y; A1.z = ray.d.z - dDva * va.z;
+        B1.x = dp.x - dpva * va.x;    B1.y = dp.y - dpva * va.y;    B1.z = dp.z - dpva * va.z;
+        double A = dot_e(A1, A1);
+        double B = 2.0 * dot_e(A1, B1);
+        double C = dot_e(B1, B1) - op.radius2;
+        double dis = B * B - 4.0 * A * C;
+        if (!(dis >= 0.0)) return false;
+        double sq = sqrt(dis);
+        double t0 = (-B - sq) / (2.0 * A), t1 = (-B + sq) / (2.0 * A);
+        if (op.flags & XRT_F_CONVEX) t = (t0 < t1) ? t0 : t1;
+        else                         t = (t0 > t1) ? t0 : t1;
+        X.x = ray.o.x + ray.d.x * t; X.y = ray.o.y + ray.d.y * t; X.z = ray.o.z + ray.d.z * t;
+        V3 q = sub3(pa, X);
+        double dummy = dot_e(q, va);
+        V3 c;
+        c.x = (pa.x - dummy * va.x) - X.x; c.y = (pa.y - dummy * va.y) - X.y; c.z = (pa.z - dummy * va.z) - X.z;
+        double m = norm3(c);
+        nrm.x = c.x / m; nrm.y = c.y / m; nrm.z = c.z / m;
+        return true;
+    }
+}
+
+// tools/xicsrt_aperture.py:108-204
+__device__ bool aperture_shape(const xrt_aperture_t& a, double x, double y)
+{
+    switch (a.shape) {
+    case XRT_AP_CIRCLE: {
+        double dx = x - a.origin[0], dy = y - a.origin[1];
+        return (dx * dx + dy * dy) < a.size[0] * a.size[0]; }
+    case XRT_AP_SQUARE:
+        return (fabs(x - a.origin[0]) < a.size[0] / 2.0) && (fabs(y - a.origin[1]) < a.size[0] / 2.0);
+    case XRT_AP_RECTANGLE:
+        return (fabs(x - a.origin[0]) < a.size[0] / 2.0) && (fabs(y - a.origin[1]) < a.size[1] / 2.0);
+    case XRT_AP_ELLIPSE: {
+        double ex = (x - a.origin[0]) / a.size[0], ey = (y - a.origin[1]) / a.size[1];
+        return (ex * ex + ey * ey) < 1.0; }
+    case XRT_AP_TRIANGLE: {
+        const double* v = a.vertices;
+        double p0x = v[0], p0y = v[1], p1x = v[2], p1y = v[3], p2x = v[4], p2y = v[5];
+        double area = 0.5 * (-p1y * p2x + p0y * (-p1x + p2x) + p0x * (p1y - p2y) + p1x * p2y);
+        double ia = 1.0 / (2.0 * area);
+        double A = ia * (p0y * p2x - p0x * p2y + (p2y - p0y) * x + (p0x - p2x) * y);
+        double B = ia * (p0x * p1y - p0y * p1x + (p0y - p1y) * x + (p1x - p0x) * y);
+        double Cc = 1.0 - A - B;
+        return (A >= 0.0) && (B >= 0.0) && (Cc >= 0.0); }
+    default: return true;
+    }
+}
+
+// TraceObject.check_bounds (optics/_TraceObject.py:180-232, tools/xicsrt_aperture.py:13-47)
+__device__ __forceinline__ bool check_bounds(const KOptic& op, const V3& X)
+{
+    V3 loc = to_local(op.R, sub3(X, ld3(op.origin)));
+    bool m = true;
+    if (op.flags & XRT_F_CHECK_SIZE) {
+        if ((op.flags & XRT_F_HAS_XSIZE) && !(fabs(loc.x) < op.half_size[0])) m = false;
+        if ((op.flags & XRT_F_HAS_YSIZE) && !(fabs(loc.y) < op.half_size[1])) m = false;
+        if ((op.flags & XRT_F_HAS_ZSIZE) && !(fabs(loc.z) < op.half_size[2])) m = false;
+    }
+    if (m && (op.flags & XRT_F_CHECK_APERTURE) && op.n_apertures > 0) {
+        bool out = true;
+        for (int a = 0; a < op.n_apertures; a++) {
+            const xrt_aperture_t ap = op.apertures[a];
+            bool t = aperture_shape(ap, loc.x, loc.y);
+            switch (ap.logic) {
+            case XRT_LOGIC_AND:  out = out && t; break;
+            case XRT_LOGIC_NOT:  out = out && !t; break;
+            case XRT_LOGIC_OR:   out = out || t; break;
+            case XRT_LOGIC_NAND: out = !(out && t); break;
+            case XRT_LOGIC_NOR:  out = !(out || t); break;
+            case XRT_LOGIC_XOR:  out = (out != t); break;
+            case XRT_LOGIC_XNOR: out = !(out != t); break;
+            }
+        }
+        m = out;
+    }
+    return m;
+}
+
+// InteractCrystal.angle_calc + rocking_curve_filter (optics/_InteractCrystal.py:96-196)
+__device__ __forceinline__ bool bragg_accept(const KOptic& op, const Ray& ray, const V3& nrm, double test)
+{
+    double bragg = asin(ray.wl / op.two_d);
+    V3 neg; neg.x = -1.0 * nrm.x; neg.y = -1.0 * nrm.y; neg.z = -1.0 * nrm.z;
+    double dt = fabs(dot_e(ray.d, neg));
+    double inc = op.half_pi - acos(dt / norm3(ray.d));
+    double p;
+    if (op.rocking_type == XRT_ROCKING_STEP) {
+        p = (fabs(inc - bragg) <= op.half_fwhm) ? 1.0 : 0.0;
+    } else {
+        double df = inc - bragg;
+        p = exp(-(df * df) / op.two_sigma2);
+    }
+    p *= op.reflectivity;
+    return p >= test;
+}
+
+// TraceObject.make_image (optics/_TraceObject.py:234-293): one hit -> one pixel
+__device__ __forceinline__ void image_hit(const KOptic& op, const V3& X, unsigned long long* images)
+{
+    V3 loc = to_local(op.R, sub3(X, ld3(op.origin)));
+    double cx = rint(loc.x / op.pixel_size + op.pixel_xoff);
+    double cy = rint(loc.y / op.pixel_size + op.pixel_yoff);
+    if (cx >= 0.0 && cx < (double)op.pixel_nx && cy >= 0.0 && cy < (double)op.pixel_ny)
+        atomicAdd(&images[op.image_offset + (long long)cx * op.pixel_ny + (long long)cy], 1ULL);
+}
+
+// --------------------------------------------------------------------------
+// workgroup scan: ordered rank of `flag` among the 256 threads (wave64 ballot,
+// mbcnt, 4 wave totals through LDS).  One barrier; `slot` alternates so that
+// back-to-back scans need no second one.
+// --------------------------------------------------------------------------
+
+__device__ __forceinline__ uint32_t wg_rank(bool flag, uint32_t* wave_tot /*[2][4]*/, int& slot,
+                                            int tid, uint32_t& total)
+{
+    unsigned long long b = __ballot(flag);
+    uint32_t lane_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+    uint32_t wave = (uint32_t)tid >> 6;
+    uint32_t* wt = wave_tot + slot * 4;
+    if ((tid & 63) == 0) wt[wave] = (uint32_t)__popcll(b);
+    __syncthreads();
+    uint32_t t0 = wt[0], t1 = wt[1], t2 = wt[2], t3 = wt[3];
+    uint32_t base = (wave > 0 ? t0 : 0u) + (wave > 1 ? t1 : 0u) + (wave > 2 ? t2 : 0u);
+    total = t0 + t1 + t2 + t3;
+    slot ^= 1;
+    return base + lane_rank;
+}
+
+// --------------------------------------------------------------------------
+// history snapshot (objects/_Dispatcher.py:162,187), layout in xicsrt_hip.h
+// --------------------------------------------------------------------------
+
+__device__ __forceinline__ void hist_write(double* hist, uint8_t* hmask, int64_t n, int e, uint32_t id,
+                                           const V3& o, const V3& d, double wl, bool alive)
+{
+    double* h = hist + (int64_t)e * XRT_HIST_COMPONENTS * n;
+    h[0 * n + id] = o.x; h[1 * n + id] = o.y; h[2 * n + id] = o.z;
+    h[3 * n + id] = d.x; h[4 * n + id] = d.y; h[5 * n + id] = d.z;
+    h[6 * n + id] = wl;  h[7 * n + id] = 1.0;
+    hmask[(int64_t)e * n + id] = alive ? 1 : 0;
+}
+
+// --------------------------------------------------------------------------
+// the propagation kernel
+// --------------------------------------------------------------------------
+
+struct KArgs {
+    const KState* states;               // [n_runs] initial generator states
+    int32_t n_runs, n_iter;
+    unsigned long long* num_out;        // [n_optics+1]
+    unsigned long long* images;         // may be null
+    uint32_t* run_counter;              // dynamic run dispenser
+    double*  hist;                      // HIST only
+    uint8_t* hmask;
+    KState*  state_out;
+};
+
+template <bool HIST>
+__global__ __launch_bounds__(XRT_TILE)
+void xrt_trace_kernel(const KScene sc, const KArgs args)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    // LDS carve-up: tile SoA (doubles first for alignment), ids, rings, small state
+    double*   tile   = reinterpret_cast<double*>(lds_raw);                       // [10][256]
+    uint32_t* tileid = reinterpret_cast<uint32_t*>(tile + XRT_TILE_COMP * XRT_TILE);   // [256]
+    uint32_t* rings  = tileid + XRT_TILE;                                        // [nh][1024]
+    const int tid = threadIdx.x;
+    const KSource& S = sc.src;
+    const int64_t N = S.n_rays;
+    const int n_arrays = S.n_arrays;
+
+    // ring index of array k (or -1), stream head ring last
+    int n_src_heads = 0;
+    int head_of[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) head_of[k] = -1;
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+        if (k < n_arrays && (S.array_used >> k) & 1u) head_of[k] = n_src_heads++;
+    uint32_t* stream = rings + n_src_heads * XRT_RING;
+    uint32_t* small = stream + XRT_RING;
+    uint32_t* wave_tot = small;                                                   // [2][4]
+    unsigned long long* cnt = reinterpret_cast<unsigned long long*>(small + 8);   // [XRT_DEV_MAX_OPTICS+1]
+    uint32_t* bcast = small + 8 + 2 * (XRT_DEV_MAX_OPTICS + 2);
+
+    int slot = 0;
+
+    for (;;) {
+        // ---- next run ------------------------------------------------------
+        if (tid == 0) bcast[0] = atomicAdd(args.run_counter, 1u);
+        __syncthreads();
+        const uint32_t run = bcast[0];
+        __syncthreads();
+        if (run >= (uint32_t)args.n_runs) break;
+
+        // initial state: s[0..624) = key, first output word = s[pos]
+        const KState* st = args.states + run;
+        for (int i = tid; i < 624; i += XRT_TILE) stream[i] = st->key[i];
+        if (tid < XRT_DEV_MAX_OPTICS + 1) cnt[tid] = 0ULL;
+        uint64_t s_gen = 624, s_next = (uint64_t)st->pos;     // uniform
+        __syncthreads();
+
+        for (int iter = 0; iter < args.n_iter; iter++) {
+            __syncthreads();
+            // ---- position the heads: walk the stream, snapshot at 2*k*N ----
+            uint64_t h_next[6], h_gen[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                h_next[k] = 0; h_gen[k] = 0;
+                if (k < n_arrays) {
+                    const uint64_t target = s_next + 2ull * (uint64_t)k * (uint64_t)N;
+                    if (head_of[k] >= 0) {
+                        while (s_gen < target) {
+                            uint64_t rem = target - s_gen;
+                            uint32_t m = rem > 512ull ? 512u : (uint32_t)rem;
+                            ring_advance(stream, s_gen, m, tid);
+                            s_gen += m;
+                        }
+                        uint32_t* r = rings + head_of[k] * XRT_RING;
+                        for (int i = tid; i < (int)XRT_RING; i += XRT_TILE) r[i] = stream[i];
+                        __syncthreads();
+                        h_next[k] = target; h_gen[k] = s_gen;
+                    }
+                }
+            }
+            {
+                const uint64_t target = s_next + 2ull * (uint64_t)n_arrays * (uint64_t)N;
+                while (s_gen < target) {
+                    uint64_t rem = target - s_gen;
+                    uint32_t m = rem > 512ull ? 512u : (uint32_t)rem;
+                    ring_advance(stream, s_gen, m, tid);
+                    s_gen += m;
+                }
+                s_next = target;
+            }
+            __syncthreads();
+
+            // ---- tiles of 256 rays in original order ------------------------
+            for (int64_t i0 = 0; i0 < N; i0 += XRT_TILE) {
+                const int64_t left = N - i0;
+                uint32_t n_in = left < XRT_TILE ? (uint32_t)left : (uint32_t)XRT_TILE;
+
+                // advance the source heads by 512 words (three phases, shared barriers)
+                for (uint32_t done = 0; done < 512u; done += 227u) {
+#pragma unroll
+                    for (int k = 0; k < 6; k++) {
+                        if (head_of[k] >= 0) {
+                            uint64_t want = h_next[k] + 512ull;
+                            uint32_t need = want > h_gen[k] ? (uint32_t)(want - h_gen[k]) : 0u;
+                            if (need > done) {
+                                uint32_t chunk = need - done;
+                                if (chunk > 227u) chunk = 227u;
+                                if ((uint32_t)tid < chunk) {
+                                    uint32_t* r = rings + head_of[k] * XRT_RING;
+                                    uint32_t n = (uint32_t)h_gen[k] + done + (uint32_t)tid;
+                                    r[n & XRT_RMASK] = mt_mix(r[(n - 624u) & XRT_RMASK], r[(n - 623u) & XRT_RMASK],
+                                                              r[(n - 227u) & XRT_RMASK]);
+                                }
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+                double u[6];
+#pragma unroll
+                for (int k = 0; k < 6; k++) {
+                    u[k] = 0.0;
+                    if (head_of[k] >= 0) {
+                        const uint32_t* r = rings + head_of[k] * XRT_RING;
+                        uint32_t n = (uint32_t)h_next[k] + 2u * (uint32_t)tid;
+                        u[k] = mt_double(r[n & XRT_RMASK], r[(n + 1u) & XRT_RMASK]);
+                        uint64_t want = h_next[k] + 512ull;
+                        if (want > h_gen[k]) h_gen[k] = want;
+                        h_next[k] = want;
+                    }
+                }
+
+                Ray ray;
+                uint32_t id = (uint32_t)(i0 + tid);
+                bool have = (uint32_t)tid < n_in;
+                source_ray(S, u, ray);
+                if (tid == 0) cnt[0] += n_in;
+                if (HIST && have) hist_write(args.hist, args.hmask, N, 0, id, ray.o, ray.d, ray.wl, true);
+
+                // ---- optics in config order (objects/_Dispatcher.py:166-196) --
+                for (int e = 0; e < sc.n_optics && n_in > 0; e++) {
+                    const KOptic& op = sc.opt[e];
+                    V3 X, nrm;
+                    X.x = X.y = X.z = 0.0; nrm = X;
+                    bool alive = false;
+                    if (have) {
+                        bool hit = intersect(op, ray, X, nrm);
+                        alive = hit && check_bounds(op, X);
+                        if (HIST && !alive) {
+                            V3 xo = X;
+                            if (!hit) { xo.x = xo.y = xo.z = __builtin_nan(""); }
+                            hist_write(args.hist, args.hmask, N, e + 1, id, xo, ray.d, ray.wl, false);
+                        }
+                    }
+                    const bool bragg = (op.interact == XRT_INTERACT_CRYSTAL) && (op.flags & XRT_F_CHECK_BRAGG);
+                    if (bragg) {
+                        // ordered live rank -> index of the ray's uniform in the stream
+                        uint32_t n_a;
+                        uint32_t rank = wg_rank(alive, wave_tot, slot, tid, n_a);
+                        if (alive) {
+                            tile[0 * XRT_TILE + rank] = X.x;     tile[1 * XRT_TILE + rank] = X.y;     tile[2 * XRT_TILE + rank] = X.z;
+                            tile[3 * XRT_TILE + rank] = ray.d.x; tile[4 * XRT_TILE + rank] = ray.d.y; tile[5 * XRT_TILE + rank] = ray.d.z;
+                            tile[6 * XRT_TILE + rank] = ray.wl;
+                            tile[7 * XRT_TILE + rank] = nrm.x;   tile[8 * XRT_TILE + rank] = nrm.y;   tile[9 * XRT_TILE + rank] = nrm.z;
+                            tileid[rank] = id;
+                        }
+                        // n_a uniforms from the stream head (np.random.uniform(0,1,n_live), :189)
+                        {
+                            uint64_t want = s_next + 2ull * n_a;
+                            uint32_t need = want > s_gen ? (uint32_t)(want - s_gen) : 0u;
+                            ring_advance(stream, s_gen, need, tid);     // ends with a barrier when need > 0
+                            if (need == 0) __syncthreads();
+                            s_gen += need;
+                        }
+                        have = (uint32_t)tid < n_a;
+                        alive = false;
+                        if (have) {
+                            X.x = tile[0 * XRT_TILE + tid];     X.y = tile[1 * XRT_TILE + tid];     X.z = tile[2 * XRT_TILE + tid];
+                            ray.d.x = tile[3 * XRT_TILE + tid]; ray.d.y = tile[4 * XRT_TILE + tid]; ray.d.z = tile[5 * XRT_TILE + tid];
+                            ray.wl = tile[6 * XRT_TILE + tid];
+                            nrm.x = tile[7 * XRT_TILE + tid];   nrm.y = tile[8 * XRT_TILE + tid];   nrm.z = tile[9 * XRT_TILE + tid];
+                            id = tileid[tid];
+                            uint32_t n = (uint32_t)s_next + 2u * (uint32_t)tid;
+                            double test = 0.0 + (1.0 - 0.0) * mt_double(stream[n & XRT_RMASK], stream[(n + 1u) & XRT_RMASK]);
+                            alive = bragg_accept(op, ray, nrm, test);
+                            if (HIST && !alive) hist_write(args.hist, args.hmask, N, e + 1, id, X, ray.d, ray.wl, false);
+                        }
+                        s_next += 2ull * n_a;
+                    }
+                    // InteractObject / InteractMirror.reflect_vectors (optics/_InteractMirror.py:29-42)
+                    if (alive) {
+                        ray.o = X;
+                        if (op.interact != XRT_INTERACT_NONE) {
+                            double dt = dot_e(ray.d, nrm);
+                            ray.d.x = ray.d.x - 2.0 * (dt * nrm.x);
+                            ray.d.y = ray.d.y - 2.0 * (dt * nrm.y);
+                            ray.d.z = ray.d.z - 2.0 * (dt * nrm.z);
+                        }
+                        if ((op.flags & XRT_F_IMAGE) && args.images) image_hit(op, X, args.images);
+                        if (HIST) hist_write(args.hist, args.hmask, N, e + 1, id, ray.o, ray.d, ray.wl, true);
+                    }
+                    // stable compaction of the survivors for the next element
+                    uint32_t n_out;
+                    uint32_t rank = wg_rank(alive, wave_tot, slot, tid, n_out);
+                    if (tid == 0) cnt[e + 1] += n_out;
+                    if (e + 1 < sc.n_optics && n_out > 0) {
+                        if (alive) {
+                            tile[0 * XRT_TILE + rank] = ray.o.x; tile[1 * XRT_TILE + rank] = ray.o.y; tile[2 * XRT_TILE + rank] = ray.o.z;
+                            tile[3 * XRT_TILE + rank] = ray.d.x; tile[4 * XRT_TILE + rank] = ray.d.y; tile[5 * XRT_TILE + rank] = ray.d.z;
+                            tile[6 * XRT_TILE + rank] = ray.wl;
+                            tileid[rank] = id;
+                        }
+                        __syncthreads();
+                        have = (uint32_t)tid < n_out;
+                        if (have) {
+                            ray.o.x = tile[0 * XRT_TILE + tid]; ray.o.y = tile[1 * XRT_TILE + tid]; ray.o.z = tile[2 * XRT_TILE + tid];
+                            ray.d.x = tile[3 * XRT_TILE + tid]; ray.d.y = tile[4 * XRT_TILE + tid]; ray.d.z = tile[5 * XRT_TILE + tid];
+                            ray.wl = tile[6 * XRT_TILE + tid];
+                            id = tileid[tid];
+                        }
+                        __syncthreads();
+                    }
+                    n_in = n_out;
+                }
+            }
+        }
+
+        // ---- run done: counters out, optional final generator state ---------
+        __syncthreads();
+        if (tid <= sc.n_optics && cnt[tid] != 0ULL) atomicAdd(&args.num_out[tid], cnt[tid]);
+        if (HIST && args.state_out) {
+            // numpy state: key = the 624-word block containing s_next, pos = offset in it
+            uint64_t block = (s_next == 0) ? 0 : ((s_next - 1) / 624ull) * 624ull;
+            uint64_t want = block + 624ull;
+            while (s_gen < want) {
+                uint64_t rem = want - s_gen;
+                uint32_t m = rem > 400ull ? 400u : (uint32_t)rem;
+                ring_advance(stream, s_gen, m, tid);
+                s_gen += m;
+            }
+            __syncthreads();
+            for (int i = tid; i < 624; i += XRT_TILE)
+                args.state_out->key[i] = stream[((uint32_t)block + (uint32_t)i) & XRT_RMASK];
+            if (tid == 0) {
+                args.state_out->pos = (int32_t)(s_next - block);
+                args.state_out->has_gauss = st->has_gauss;
+                args.state_out->gauss = st->gauss;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// np.random.seed(int) -> init_genrand, one thread per run (xicsrt_raytrace.py:111)
+__global__ void xrt_seed_kernel(const uint32_t* seeds, KState* states, int n_runs)
+{
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_runs) return;
+    uint32_t s = seeds[r];
+    KState* st = states + r;
+    for (int i = 0; i < 624; i++) {
+        st->key[i] = s;
+        s = 1812433253u * (s ^ (s >> 30)) + (uint32_t)(i + 1);
+    }
+    st->pos = 624;
+    st->has_gauss = 0;
+    st->gauss = 0.0;
+}
+
+// ==========================================================================
+// host side of the C ABI
+// ==========================================================================
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, const char* a = "")
+{
+    snprintf(g_err, sizeof(g_err), fmt, a);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                              \
+    do {                                                                           \
+        hipError_t e_ = (expr);                                                    \
+        if (e_ != hipSuccess) return fail(-10, #expr ": %s", hipGetErrorString(e_)); \
+    } while (0)
+
+static bool timing_on = false;
+static double timing_ms = 0.0;
+static int64_t timing_launches = 0;
+static const int TIMING_MAX = 64;
+static hipEvent_t timing_ev[TIMING_MAX][2];
+static int timing_n = 0;
+
+extern "C" int xrt_abi_version(void) { return XRT_ABI_VERSION; }
+extern "C" const char* xrt_last_error(void) { return g_err; }
+extern "C" size_t xrt_sizeof_scene(void) { return sizeof(xrt_scene_t); }
+
+extern "C" int xrt_device_count(int* count)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(-10, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = n;
+    return 0;
+}
+
+extern "C" int xrt_scene_check(const xrt_scene_t* sc)
+{
+    if (!sc) return fail(-1, "%s", "scene is NULL");
+    if (sc->n_optics < 0 || sc->n_optics > XRT_DEV_MAX_OPTICS)
+        return fail(-2, "%s", "device path supports at most 8 optics");
+    const xrt_source_t& s = sc->source;
+    if (s.intensity < 0) return fail(-2, "%s", "negative intensity");
+    if (s.spatial_dist != XRT_SPATIAL_UNIFORM)
+        return fail(-3, "%s", "spatial_dist 'gaussian' is not implemented on the device path");
+    if (s.angular_dist != XRT_ANG_ISOTROPIC && s.angular_dist != XRT_ANG_FLAT && s.angular_dist != XRT_ANG_FLAT_XY)
+        return fail(-3, "%s", "angular_dist 'isotropic_xy' is not implemented on the device path");
+    if (s.wavelength_dist == XRT_WL_NORMAL)
+        return fail(-3, "%s", "gaussian (temperature-only) wavelength sampling is not implemented on the device path");
+    if (s.wavelength_dist == XRT_WL_VOIGT && (s.voigt_n < 2 || !s.voigt_cdf || !s.voigt_x))
+        return fail(-2, "%s", "voigt table missing");
+    int n_bragg = 0;
+    for (int e = 0; e < sc->n_optics; e++) {
+        const xrt_optic_t& o = sc->optics[e];
+        if (o.interact == XRT_INTERACT_CRYSTAL && (o.flags & XRT_F_CHECK_BRAGG)) n_bragg++;
+        if (n_bragg > 1)
+            // the reference draws optic k's uniforms for ALL rays before optic k+1's
+            // (array-sequential stream); needs the staged multi-pass path
+            return fail(-3, "%s", "more than one Bragg-checking optic is not implemented on the device path");
+        if (o.shape != XRT_SHAPE_PLANE && o.shape != XRT_SHAPE_SPHERE && o.shape != XRT_SHAPE_CYLINDER)
+            return fail(-3, "%s", "optic shape is not implemented on the device path");
+        if (o.interact < XRT_INTERACT_NONE || o.interact > XRT_INTERACT_CRYSTAL)
+            return fail(-3, "%s", "optic interaction is not implemented on the device path");
+        if (o.flags & XRT_F_TRACE_LOCAL)
+            return fail(-3, "%s", "trace_local is not implemented on the device path");
+        if (o.n_apertures < 0 || o.n_apertures > XRT_MAX_APERTURES) return fail(-2, "%s", "bad aperture count");
+        if ((o.flags & XRT_F_IMAGE) && (o.pixel_nx <= 0 || o.pixel_ny <= 0 || o.image_offset < 0 ||
+                                        o.image_offset + (int64_t)o.pixel_nx * o.pixel_ny > sc->image_bins))
+            return fail(-2, "%s", "image layout inconsistent");
+    }
+    return 0;
+}
+
+// workspace layout: [run counter 256 B][apertures][voigt tables][states]
+static size_t ws_off_apertures() { return 256; }
+static size_t ws_off_voigt() { return ws_off_apertures() + sizeof(xrt_aperture_t) * XRT_MAX_APERTURES * XRT_DEV_MAX_OPTICS; }
+static size_t ws_off_states(const xrt_scene_t* sc)
+{
+    size_t v = ws_off_voigt() + 2 * sizeof(double) * (size_t)(sc->source.voigt_n > 0 ? sc->source.voigt_n : 0);
+    return (v + 255) & ~(size_t)255;
+}
+
+extern "C" size_t xrt_workspace_bytes(const xrt_scene_t* sc, int32_t n_runs)
+{
+    if (!sc || n_runs < 0) return 0;
+    return ws_off_states(sc) + sizeof(KState) * (size_t)(n_runs > 0 ? n_runs : 1) + sizeof(uint32_t) * (size_t)(n_runs > 0 ? n_runs : 1) + 256;
+}
+
+static void build_kscene(const xrt_scene_t* sc, char* ws, KScene* k)
+{
+    memset(k, 0, sizeof(*k));
+    const xrt_source_t& s = sc->source;
+    KSource& d = k->src;
+    d.kind = s.kind; d.angular_dist = s.angular_dist; d.wavelength_dist = s.wavelength_dist;
+    d.has_velocity = s.has_velocity;
+    d.n_rays = s.intensity;
+    for (int i = 0; i < 3; i++) {
+        d.origin[i] = s.origin[i];
+        d.xaxis[i] = s.orientation[i]; d.yaxis[i] = s.orientation[3 + i]; d.zaxis[i] = s.orientation[6 + i];
+        // np.random.uniform(-1*size/2, size/2, n) (_XicsrtSourceGeneric.py:233-235)
+        const double low = -1.0 * s.size[i] / 2.0, high = s.size[i] / 2.0;
+        d.low[i] = low; d.range[i] = high - low;
+        d.axis[i] = s.axis[i]; d.velocity[i] = s.velocity[i];
+    }
+    for (int i = 0; i < 9; i++) d.basis[i] = s.basis[i];
+    for (int i = 0; i < 5; i++) d.ang[i] = s.ang[i];
+    d.two_pi = s.two_pi; d.wavelength = s.wavelength; d.wl_a = s.wl_a; d.wl_b = s.wl_b;
+    d.light_speed = s.light_speed;
+    d.voigt_n = s.voigt_n;
+    d.voigt_cdf = reinterpret_cast<const double*>(ws + ws_off_voigt());
+    d.voigt_x = d.voigt_cdf + (s.voigt_n > 0 ? s.voigt_n : 0);
+    const bool wl_array = (s.wavelength_dist == XRT_WL_UNIFORM || s.wavelength_dist == XRT_WL_VOIGT);
+    d.n_arrays = wl_array ? 6 : 5;
+    d.array_used = 0;
+    for (int i = 0; i < 3; i++) if (s.size[i] != 0.0) d.array_used |= 1u << i;
+    d.array_used |= (1u << 3) | (1u << 4);
+    if (wl_array) d.array_used |= 1u << 5;
+
+    k->n_optics = sc->n_optics;
+    for (int e = 0; e < sc->n_optics; e++) {
+        const xrt_optic_t& o = sc->optics[e];
+        KOptic& q = k->opt[e];
+        q.shape = o.shape; q.interact = o.interact; q.flags = o.flags; q.rocking_type = o.rocking_type;
+        for (int i = 0; i < 3; i++) { q.origin[i] = o.origin[i]; q.half_size[i] = o.half_size[i]; q.center[i] = o.center[i]; }
+        for (int i = 0; i < 9; i++) q.R[i] = o.orientation[i];
+        q.radius = o.radius; q.radius2 = o.radius2;
+        q.two_d = o.two_d; q.reflectivity = o.reflectivity; q.half_fwhm = o.rocking_half_fwhm;
+        q.two_sigma2 = o.rocking_2sigma2; q.half_pi = o.half_pi;
+        q.pixel_size = o.pixel_size; q.pixel_xoff = o.pixel_xoff; q.pixel_yoff = o.pixel_yoff;
+        q.pixel_nx = o.pixel_nx; q.pixel_ny = o.pixel_ny; q.image_offset = o.image_offset;
+        q.n_apertures = o.n_apertures;
+        q.apertures = reinterpret_cast<const xrt_aperture_t*>(ws + ws_off_apertures()) + (size_t)e * XRT_MAX_APERTURES;
+    }
+}
+
+static size_t lds_bytes(const KScene& k)
+{
+    int heads = 1;
+    for (int i = 0; i < k.src.n_arrays; i++) if ((k.src.array_used >> i) & 1u) heads++;
+    size_t b = sizeof(double) * XRT_TILE_COMP * XRT_TILE + sizeof(uint32_t) * XRT_TILE;
+    b += sizeof(uint32_t) * XRT_RING * (size_t)heads;
+    b += sizeof(uint32_t) * (8 + 2 * (XRT_DEV_MAX_OPTICS + 2) + 8);
+    return (b + 15) & ~(size_t)15;
+}
+
+template <bool HIST>
+static int launch(const xrt_scene_t* sc, char* ws, const KArgs& a_in, int n_runs, hipStream_t stream)
+{
+    KScene ks;
+    build_kscene(sc, ws, &ks);
+    KArgs a = a_in;
+    a.run_counter = reinterpret_cast<uint32_t*>(ws);
+    HIP_TRY(hipMemsetAsync(ws, 0, 256, stream));
+    // apertures and voigt tables: pageable host memory -> staged copies, ordered on the stream
+    for (int e = 0; e < sc->n_optics; e++)
+        if (sc->optics[e].n_apertures > 0)
+            HIP_TRY(hipMemcpyAsync(ws + ws_off_apertures() + sizeof(xrt_aperture_t) * XRT_MAX_APERTURES * (size_t)e,
+                                   sc->optics[e].apertures, sizeof(xrt_aperture_t) * (size_t)sc->optics[e].n_apertures,
+                                   hipMemcpyHostToDevice, stream));
+    if (sc->source.wavelength_dist == XRT_WL_VOIGT) {
+        size_t nb = sizeof(double) * (size_t)sc->source.voigt_n;
+        HIP_TRY(hipMemcpyAsync(ws + ws_off_voigt(), sc->source.voigt_cdf, nb, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(ws + ws_off_voigt() + nb, sc->source.voigt_x, nb, hipMemcpyHostToDevice, stream));
+    }
+    const size_t lds = lds_bytes(ks);
+    auto kern = xrt_trace_kernel<HIST>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int dev = 0, cus = 256, per_cu = 1;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, XRT_TILE, lds));
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 8) per_cu = 8;
+    int grid = cus * per_cu;
+    if (grid > n_runs) grid = n_runs;
+    if (grid < 1) grid = 1;
+    int ti = -1;
+    if (timing_on && timing_n < TIMING_MAX) {
+        ti = timing_n++;
+        HIP_TRY(hipEventCreate(&timing_ev[ti][0]));
+        HIP_TRY(hipEventCreate(&timing_ev[ti][1]));
+        HIP_TRY(hipEventRecord(timing_ev[ti][0], stream));
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(XRT_TILE), lds, stream, ks, a);
+    HIP_TRY(hipGetLastError());
+    if (ti >= 0) HIP_TRY(hipEventRecord(timing_ev[ti][1], stream));
+    return 0;
+}
+
+extern "C" int xrt_trace(const xrt_scene_t* sc, const uint32_t* seeds, int32_t n_runs, int32_t n_iter,
+                         uint64_t* num_out, uint64_t* images, void* workspace, size_t workspace_bytes, void* stream_)
+{
+    int st = xrt_scene_check(sc);
+    if (st) return st;
+    if (n_runs <= 0 || n_iter <= 0) return 0;
+    if (!seeds || !num_out || !workspace) return fail(-1, "%s", "NULL argument");
+    if (workspace_bytes < xrt_workspace_bytes(sc, n_runs)) return fail(-4, "%s", "workspace too small");
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    char* ws = reinterpret_cast<char*>(workspace);
+    KState* states = reinterpret_cast<KState*>(ws + ws_off_states(sc));
+    uint32_t* d_seeds = reinterpret_cast<uint32_t*>(states + n_runs);
+    HIP_TRY(hipMemcpyAsync(d_seeds, seeds, sizeof(uint32_t) * (size_t)n_runs, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(xrt_seed_kernel, dim3((n_runs + 63) / 64), dim3(64), 0, stream, d_seeds, states, n_runs);
+    HIP_TRY(hipGetLastError());
+    KArgs a;
+    memset(&a, 0, sizeof(a));
+    a.states = states; a.n_runs = n_runs; a.n_iter = n_iter;
+    a.num_out = reinterpret_cast<unsigned long long*>(num_out);
+    a.images = reinterpret_cast<unsigned long long*>(images);
+    return launch<false>(sc, ws, a, n_runs, stream);
+}
+
+extern "C" int xrt_trace_history(const xrt_scene_t* sc, const xrt_rng_state_t* state_in,
+                                 uint64_t* num_out, uint64_t* images, double* rays, uint8_t* mask, void* state_out,
+                                 void* workspace, size_t workspace_bytes, void* stream_)
+{
+    int st = xrt_scene_check(sc);
+    if (st) return st;
+    if (!state_in || !num_out || !workspace || !rays || !mask) return fail(-1, "%s", "NULL argument");
+    if (state_in->pos < 0 || state_in->pos > 624) return fail(-2, "%s", "generator position out of range");
+    if (workspace_bytes < xrt_workspace_bytes(sc, 1)) return fail(-4, "%s", "workspace too small");
+    static_assert(sizeof(KState) == sizeof(xrt_rng_state_t), "state layout");
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    char* ws = reinterpret_cast<char*>(workspace);
+    KState* states = reinterpret_cast<KState*>(ws + ws_off_states(sc));
+    HIP_TRY(hipMemcpyAsync(states, state_in, sizeof(KState), hipMemcpyHostToDevice, stream));
+    KArgs a;
+    memset(&a, 0, sizeof(a));
+    a.states = states; a.n_runs = 1; a.n_iter = 1;
+    a.num_out = reinterpret_cast<unsigned long long*>(num_out);
+    a.images = reinterpret_cast<unsigned long long*>(images);
+    a.hist = rays; a.hmask = mask; a.state_out = reinterpret_cast<KState*>(state_out);
+    return launch<true>(sc, ws, a, 1, stream);
+}
+
+extern "C" int xrt_timing_begin(void)
+{
+    for (int i = 0; i < timing_n; i++) { (void)hipEventDestroy(timing_ev[i][0]); (void)hipEventDestroy(timing_ev[i][1]); }
+    timing_n = 0; timing_ms = 0.0; timing_launches = 0; timing_on = true;
+    return 0;
+}
+
+extern "C" int xrt_timing_end(double* kernel_ms, int64_t* launches)
+{
+    timing_on = false;
+    double total = 0.0;
+    for (int i = 0; i < timing_n; i++) {
+        HIP_TRY(hipEventSynchronize(timing_ev[i][1]));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, timing_ev[i][0], timing_ev[i][1]));
+        total += ms;
+        (void)hipEventDestroy(timing_ev[i][0]); (void)hipEventDestroy(timing_ev[i][1]);
+    }
+    if (kernel_ms) *kernel_ms = total;
+    if (launches) *launches = timing_n;
+    timing_n = 0;
+    return 0;
+}

@@ -20,7 +20,7 @@ import ctypes as C
 
 import numpy as np
 
-XRT_ABI_VERSION = 3
+XRT_ABI_VERSION = 4
 XRT_MAX_OPTICS = 16
 XRT_MAX_APERTURES = 8
 XRT_HIST_COMPONENTS = 8
@@ -52,7 +52,7 @@ class Source(C.Structure):
                 ('intensity', C.c_int64),
                 ('origin', C.c_double * 3), ('orientation', C.c_double * 9),
                 ('size', C.c_double * 3), ('spatial_A', C.c_double * 9),
-                ('axis', C.c_double * 3), ('ang', C.c_double * 5),
+                ('axis', C.c_double * 3), ('basis', C.c_double * 9), ('ang', C.c_double * 5),
                 ('two_pi', C.c_double), ('wavelength', C.c_double),
                 ('wl_a', C.c_double), ('wl_b', C.c_double),
                 ('has_velocity', C.c_int32), ('voigt_n', C.c_int32),
@@ -180,6 +180,17 @@ def flatten_source(obj, out, keep):
     if axis is None:
         raise Exception('source cone axis (%s) is not set' % obj.cone_axis_rule)
     _vec(out.axis, axis)
+    _vec(out.basis, np.zeros(9))
+    if obj.cone_axis_rule != 'target':
+        # make_normal + random_direction frame for a single (shared) cone axis
+        array = np.empty((1, 3))
+        array[:] = axis
+        normal = array / np.linalg.norm(array, axis=1)[:, np.newaxis]
+        o_1 = np.cross(normal, p['xaxis']) + np.cross(normal, p['zaxis'])
+        o_1 /= np.linalg.norm(o_1, axis=1)[:, np.newaxis]
+        o_2 = np.cross(normal, o_1)
+        o_2 /= np.linalg.norm(o_2, axis=1)[:, np.newaxis]
+        _vec(out.basis, np.concatenate([o_2[0], o_1[0], normal[0]]))
 
     spread = p['spread']
     ang = np.zeros(5)
