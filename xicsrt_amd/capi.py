@@ -10,7 +10,7 @@ import os
 from . import scene as _scene
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libxicsrt_hip.so')
+LIB_PATH = os.environ.get('XICSRT_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libxicsrt_hip.so')
 
 EXPORTS = (
     'xrt_abi_version', 'xrt_last_error', 'xrt_sizeof_scene', 'xrt_scene_check',

@@ -96,6 +96,16 @@ struct KState {             // xrt_rng_state_t layout
     double   gauss;
 };
 
+// A positioned generator: sliding window of the MT19937 state sequence in a
+// 1024-word ring (slot = index & 1023) holding s[gen-1024, gen); `next` is the
+// index of the next word to hand out.
+struct KStream {
+    uint32_t ring[1024];
+    uint64_t gen;
+    uint64_t next;
+    uint64_t pad[2];
+};
+
 // --------------------------------------------------------------------------
 // MT19937 (numpy legacy RandomState)
 // --------------------------------------------------------------------------
@@ -120,6 +130,15 @@ __device__ __forceinline__ double mt_double(uint32_t w0, uint32_t w1)
 {
     uint32_t a = mt_temper(w0) >> 5, b = mt_temper(w1) >> 6;
     return ((double)a * 67108864.0 + (double)b) * (1.0 / 9007199254740992.0);
+}
+
+// Values that are the same in every lane but come from memory: tell the compiler
+// (scalar registers, scalar branches) with readfirstlane.
+__device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t uni64(uint64_t v)
+{
+    uint32_t lo = uni32((uint32_t)v), hi = uni32((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
 }
 
 // Advance ring `r` (holding s[.. gen)) by `count` words, all threads of the
@@ -201,6 +220,7 @@ struct Ray {
 };
 
 // u[k] = the k-th array's double for this ray (0.0 for arrays whose value cannot matter)
+template <bool FULL>
 __device__ __forceinline__ void source_ray(const KSource& s, const double* u, Ray& ray)
 {
     // generate_origin (:229-255): origin + x*xaxis + y*yaxis + z*zaxis, left to right
@@ -213,7 +233,7 @@ __device__ __forceinline__ void source_ray(const KSource& s, const double* u, Ra
 
     // make_normal + basis (:262-285; Directed :46-50; Focused :40-44)
     V3 n, o1, o2;
-    if (s.kind == XRT_SRC_FOCUSED) {
+    if (FULL && s.kind == XRT_SRC_FOCUSED) {
         V3 a = sub3(ld3(s.axis), ray.o);
         double m = norm3(a);
         n.x = a.x / m; n.y = a.y / m; n.z = a.z / m;
@@ -230,7 +250,7 @@ __device__ __forceinline__ void source_ray(const KSource& s, const double* u, Ra
 
     // local direction about +z (tools/xicsrt_spread.py:80-294)
     double l0, l1, l2;
-    if (s.angular_dist == XRT_ANG_ISOTROPIC) {
+    if (!FULL || s.angular_dist == XRT_ANG_ISOTROPIC) {
         double z = s.ang[0] + (1.0 - s.ang[0]) * u[3];
         double phi = 0.0 + (s.two_pi - 0.0) * u[4];
         double st = sqrt(1.0 - z * z);
@@ -264,7 +284,7 @@ __device__ __forceinline__ void source_ray(const KSource& s, const double* u, Ra
     double wl;
     if (s.wavelength_dist == XRT_WL_UNIFORM) {
         wl = s.wl_a + s.wl_b * u[5];
-    } else if (s.wavelength_dist == XRT_WL_VOIGT) {
+    } else if (FULL && s.wavelength_dist == XRT_WL_VOIGT) {
         double y = s.wl_a + s.wl_b * u[5];
         wl = np_interp(y, s.voigt_cdf, s.voigt_x, s.voigt_n) + s.wavelength;
     } else {
@@ -283,6 +303,7 @@ __device__ __forceinline__ void source_ray(const KSource& s, const double* u, Ra
 
 // Shape*.intersect: distance, location, normal.  Returns false when the ray has
 // no intersection (mask &= ... in the reference).
+template <bool FULL>
 __device__ __forceinline__ bool intersect(const KOptic& op, const Ray& ray, V3& X, V3& nrm)
 {
     double t;
@@ -295,7 +316,7 @@ __device__ __forceinline__ bool intersect(const KOptic& op, const Ray& ray, V3& 
         nrm = za;
         X.x = ray.o.x + ray.d.x * t; X.y = ray.o.y + ray.d.y * t; X.z = ray.o.z + ray.d.z * t;
         return true;
-    } else if (op.shape == XRT_SHAPE_SPHERE) {
+    } else if (!FULL || op.shape == XRT_SHAPE_SPHERE) {
         // optics/_ShapeSphere.py:52-106
         V3 c = ld3(op.center);
         V3 L = sub3(c, ray.o);
@@ -367,6 +388,7 @@ __device__ bool aperture_shape(const xrt_aperture_t& a, double x, double y)
 }
 
 // TraceObject.check_bounds (optics/_TraceObject.py:180-232, tools/xicsrt_aperture.py:13-47)
+template <bool FULL>
 __device__ __forceinline__ bool check_bounds(const KOptic& op, const V3& X)
 {
     V3 loc = to_local(op.R, sub3(X, ld3(op.origin)));
@@ -376,7 +398,7 @@ __device__ __forceinline__ bool check_bounds(const KOptic& op, const V3& X)
         if ((op.flags & XRT_F_HAS_YSIZE) && !(fabs(loc.y) < op.half_size[1])) m = false;
         if ((op.flags & XRT_F_HAS_ZSIZE) && !(fabs(loc.z) < op.half_size[2])) m = false;
     }
-    if (m && (op.flags & XRT_F_CHECK_APERTURE) && op.n_apertures > 0) {
+    if (FULL && m && (op.flags & XRT_F_CHECK_APERTURE) && op.n_apertures > 0) {
         bool out = true;
         for (int a = 0; a < op.n_apertures; a++) {
             const xrt_aperture_t ap = op.apertures[a];
@@ -441,7 +463,7 @@ __device__ __forceinline__ uint32_t wg_rank(bool flag, uint32_t* wave_tot /*[2][
     __syncthreads();
     uint32_t t0 = wt[0], t1 = wt[1], t2 = wt[2], t3 = wt[3];
     uint32_t base = (wave > 0 ? t0 : 0u) + (wave > 1 ? t1 : 0u) + (wave > 2 ? t2 : 0u);
-    total = t0 + t1 + t2 + t3;
+    total = uni32(t0 + t1 + t2 + t3);
     slot ^= 1;
     return base + lane_rank;
 }
@@ -461,46 +483,159 @@ __device__ __forceinline__ void hist_write(double* hist, uint8_t* hmask, int64_t
 }
 
 // --------------------------------------------------------------------------
+// generator set-up kernels
+// --------------------------------------------------------------------------
+
+// np.random.seed(int) -> init_genrand, one thread per run (xicsrt_raytrace.py:111)
+__global__ void xrt_seed_kernel(const uint32_t* seeds, KStream* streams, int n_runs)
+{
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_runs) return;
+    uint32_t s = seeds[r];
+    KStream* st = streams + r;
+    for (int i = 0; i < 624; i++) {
+        st->ring[i] = s;
+        s = 1812433253u * (s ^ (s >> 30)) + (uint32_t)(i + 1);
+    }
+    st->gen = 624;
+    st->next = 624;
+}
+
+// explicit numpy state -> stream (xrt_trace_history)
+__global__ void xrt_import_state_kernel(const KState* in, KStream* out)
+{
+    for (int i = threadIdx.x; i < 624; i += blockDim.x) out->ring[i] = in->key[i];
+    if (threadIdx.x == 0) { out->gen = 624; out->next = (uint64_t)in->pos; }
+}
+
+// One wave walks one run's stream forward (no tempering, no workgroup barriers:
+// LDS operations of a single wave execute in order) and snapshots the window
+// wherever a source array starts: array k of N doubles begins 2*k*N words after
+// the iteration's first word.  The stream itself is
+// left at the first word after the source arrays (the Bragg uniforms).
+__device__ __forceinline__ void wave_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ void wave_walk(uint32_t* ring, uint64_t& gen, uint64_t target, int lane)
+{
+    // full chunks of 192 (<= 227 words are independent): all nine reads in flight
+    // together, then the three results are written
+    while (gen < target && target - gen >= 192ull) {
+        const uint32_t n0 = (uint32_t)gen + (uint32_t)lane, n1 = n0 + 64u, n2 = n0 + 128u;
+        const uint32_t a0 = ring[(n0 - 624u) & XRT_RMASK], b0 = ring[(n0 - 623u) & XRT_RMASK], c0 = ring[(n0 - 227u) & XRT_RMASK];
+        const uint32_t a1 = ring[(n1 - 624u) & XRT_RMASK], b1 = ring[(n1 - 623u) & XRT_RMASK], c1 = ring[(n1 - 227u) & XRT_RMASK];
+        const uint32_t a2 = ring[(n2 - 624u) & XRT_RMASK], b2 = ring[(n2 - 623u) & XRT_RMASK], c2 = ring[(n2 - 227u) & XRT_RMASK];
+        ring[n0 & XRT_RMASK] = mt_mix(a0, b0, c0);
+        ring[n1 & XRT_RMASK] = mt_mix(a1, b1, c1);
+        ring[n2 & XRT_RMASK] = mt_mix(a2, b2, c2);
+        wave_fence();
+        gen += 192ull;
+    }
+    if (gen < target) {
+        const uint32_t m = (uint32_t)(target - gen);
+#pragma unroll
+        for (uint32_t j = 0; j < 3; j++) {
+            uint32_t o = j * 64u + (uint32_t)lane;
+            if (o < m) {
+                uint32_t n = (uint32_t)gen + o;
+                ring[n & XRT_RMASK] = mt_mix(ring[(n - 624u) & XRT_RMASK], ring[(n - 623u) & XRT_RMASK],
+                                             ring[(n - 227u) & XRT_RMASK]);
+            }
+        }
+        wave_fence();
+        gen = target;
+    }
+}
+
+__global__ __launch_bounds__(256)
+void xrt_seek_kernel(KStream* streams, KStream* heads, int n_runs, int n_arrays, uint32_t array_used,
+                     int n_src_heads, int64_t n_rays)
+{
+    __shared__ uint32_t rings[4][XRT_RING];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int run = blockIdx.x * 4 + wave;
+    if (run >= n_runs) return;
+    uint32_t* ring = rings[wave];
+    KStream* st = streams + run;
+    for (int i = lane; i < (int)XRT_RING; i += 64) ring[i] = st->ring[i];
+    uint64_t gen = uni64(st->gen);
+    const uint64_t next = uni64(st->next);
+    wave_fence();
+    int h = 0;
+    for (int k = 0; k <= n_arrays; k++) {
+        const uint64_t target = next + 2ull * (uint64_t)k * (uint64_t)n_rays;
+        const bool snap = (k < n_arrays) && ((array_used >> k) & 1u);
+        if (!snap && k < n_arrays) continue;
+        wave_walk(ring, gen, target, lane);
+        KStream* out = (k < n_arrays) ? (heads + (size_t)run * n_src_heads + h) : st;
+        for (int i = lane; i < (int)XRT_RING; i += 64) out->ring[i] = ring[i];
+        if (lane == 0) { out->gen = gen; out->next = target; }
+        if (k < n_arrays) h++;
+    }
+}
+
+// stream -> numpy state: key = the 624-word block that contains `next`
+__global__ __launch_bounds__(64)
+void xrt_export_state_kernel(const KStream* in, const KState* orig, KState* out)
+{
+    __shared__ uint32_t ring[XRT_RING];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < (int)XRT_RING; i += 64) ring[i] = in->ring[i];
+    uint64_t gen = uni64(in->gen);
+    const uint64_t next = uni64(in->next);
+    wave_fence();
+    const uint64_t block = (next == 0) ? 0 : ((next - 1) / 624ull) * 624ull;
+    wave_walk(ring, gen, block + 624ull, lane);
+    for (int i = lane; i < 624; i += 64) out->key[i] = ring[((uint32_t)block + (uint32_t)i) & XRT_RMASK];
+    if (lane == 0) {
+        out->pos = (int32_t)(next - block);
+        out->has_gauss = orig->has_gauss;
+        out->gauss = orig->gauss;
+    }
+}
+
+// --------------------------------------------------------------------------
 // the propagation kernel
 // --------------------------------------------------------------------------
 
 struct KArgs {
-    const KState* states;               // [n_runs] initial generator states
-    int32_t n_runs, n_iter;
+    KStream* streams;                   // [n_runs] stream heads, updated in place
+    const KStream* heads;               // [n_runs][n_src_heads] positioned source heads
+    int32_t n_runs, n_src_heads;
     unsigned long long* num_out;        // [n_optics+1]
     unsigned long long* images;         // may be null
     uint32_t* run_counter;              // dynamic run dispenser
     double*  hist;                      // HIST only
     uint8_t* hmask;
-    KState*  state_out;
 };
 
-template <bool HIST>
-__global__ __launch_bounds__(XRT_TILE)
+#ifndef XRT_WAVES_PER_EU
+#define XRT_WAVES_PER_EU 4
+#endif
+
+// HIST: write the per-element history.  FULL: every source/shape/aperture
+// feature; !FULL: the lean variant (isotropic cone, shared cone axis, constant
+// or uniform wavelength, plane/sphere, no apertures) with lower register use.
+template <bool HIST, bool FULL>
+__global__ __launch_bounds__(XRT_TILE, XRT_WAVES_PER_EU)
 void xrt_trace_kernel(const KScene sc, const KArgs args)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    // LDS carve-up: tile SoA (doubles first for alignment), ids, rings, small state
-    double*   tile   = reinterpret_cast<double*>(lds_raw);                       // [10][256]
+    double*   tile   = reinterpret_cast<double*>(lds_raw);                             // [10][256]
     uint32_t* tileid = reinterpret_cast<uint32_t*>(tile + XRT_TILE_COMP * XRT_TILE);   // [256]
-    uint32_t* rings  = tileid + XRT_TILE;                                        // [nh][1024]
+    uint32_t* rings  = tileid + XRT_TILE;                                              // [nh+1][1024]
     const int tid = threadIdx.x;
     const KSource& S = sc.src;
     const int64_t N = S.n_rays;
-    const int n_arrays = S.n_arrays;
-
-    // ring index of array k (or -1), stream head ring last
-    int n_src_heads = 0;
-    int head_of[6];
-#pragma unroll
-    for (int k = 0; k < 6; k++) head_of[k] = -1;
-#pragma unroll
-    for (int k = 0; k < 6; k++)
-        if (k < n_arrays && (S.array_used >> k) & 1u) head_of[k] = n_src_heads++;
-    uint32_t* stream = rings + n_src_heads * XRT_RING;
+    const int nh = args.n_src_heads;
+    uint32_t* stream = rings + nh * XRT_RING;
     uint32_t* small = stream + XRT_RING;
-    uint32_t* wave_tot = small;                                                   // [2][4]
-    unsigned long long* cnt = reinterpret_cast<unsigned long long*>(small + 8);   // [XRT_DEV_MAX_OPTICS+1]
+    uint32_t* wave_tot = small;                                                        // [2][4]
+    unsigned long long* cnt = reinterpret_cast<unsigned long long*>(small + 8);        // [XRT_DEV_MAX_OPTICS+1]
     uint32_t* bcast = small + 8 + 2 * (XRT_DEV_MAX_OPTICS + 2);
 
     int slot = 0;
@@ -509,227 +644,209 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
         // ---- next run ------------------------------------------------------
         if (tid == 0) bcast[0] = atomicAdd(args.run_counter, 1u);
         __syncthreads();
-        const uint32_t run = bcast[0];
-        __syncthreads();
+        const uint32_t run = uni32(bcast[0]);
         if (run >= (uint32_t)args.n_runs) break;
 
-        // initial state: s[0..624) = key, first output word = s[pos]
-        const KState* st = args.states + run;
-        for (int i = tid; i < 624; i += XRT_TILE) stream[i] = st->key[i];
-        if (tid < XRT_DEV_MAX_OPTICS + 1) cnt[tid] = 0ULL;
-        uint64_t s_gen = 624, s_next = (uint64_t)st->pos;     // uniform
-        __syncthreads();
-
-        for (int iter = 0; iter < args.n_iter; iter++) {
-            __syncthreads();
-            // ---- position the heads: walk the stream, snapshot at 2*k*N ----
-            uint64_t h_next[6], h_gen[6];
+        // ---- load the positioned heads and the stream head ----------------
+        // gen/pos are kept modulo 2^32 (ring slots only need the low 10 bits,
+        // differences stay < 2^11); the stream's 64-bit position is rebuilt
+        // from the number of words consumed.
+        uint32_t hgen[6], hpos[6];
+        {
+            int h = 0;
 #pragma unroll
             for (int k = 0; k < 6; k++) {
-                h_next[k] = 0; h_gen[k] = 0;
-                if (k < n_arrays) {
-                    const uint64_t target = s_next + 2ull * (uint64_t)k * (uint64_t)N;
-                    if (head_of[k] >= 0) {
-                        while (s_gen < target) {
-                            uint64_t rem = target - s_gen;
-                            uint32_t m = rem > 512ull ? 512u : (uint32_t)rem;
-                            ring_advance(stream, s_gen, m, tid);
-                            s_gen += m;
-                        }
-                        uint32_t* r = rings + head_of[k] * XRT_RING;
-                        for (int i = tid; i < (int)XRT_RING; i += XRT_TILE) r[i] = stream[i];
-                        __syncthreads();
-                        h_next[k] = target; h_gen[k] = s_gen;
-                    }
+                hgen[k] = 0; hpos[k] = 0;
+                if ((S.array_used >> k) & 1u) {
+                    const KStream* src = args.heads + (size_t)run * nh + h;
+                    uint32_t* r = rings + h * XRT_RING;
+                    for (int i = tid; i < (int)XRT_RING; i += XRT_TILE) r[i] = src->ring[i];
+                    hgen[k] = uni32((uint32_t)src->gen);
+                    hpos[k] = uni32((uint32_t)src->next);
+                    h++;
                 }
             }
-            {
-                const uint64_t target = s_next + 2ull * (uint64_t)n_arrays * (uint64_t)N;
-                while (s_gen < target) {
-                    uint64_t rem = target - s_gen;
-                    uint32_t m = rem > 512ull ? 512u : (uint32_t)rem;
-                    ring_advance(stream, s_gen, m, tid);
-                    s_gen += m;
-                }
-                s_next = target;
-            }
-            __syncthreads();
+        }
+        KStream* st = args.streams + run;
+        for (int i = tid; i < (int)XRT_RING; i += XRT_TILE) stream[i] = st->ring[i];
+        const uint64_t s_next0 = uni64(st->next), s_gen0 = uni64(st->gen);
+        uint32_t sgen = (uint32_t)s_gen0, spos = (uint32_t)s_next0;
+        uint64_t s_used = 0;
+        if (tid < XRT_DEV_MAX_OPTICS + 1) cnt[tid] = 0ULL;
+        __syncthreads();
 
-            // ---- tiles of 256 rays in original order ------------------------
-            for (int64_t i0 = 0; i0 < N; i0 += XRT_TILE) {
-                const int64_t left = N - i0;
-                uint32_t n_in = left < XRT_TILE ? (uint32_t)left : (uint32_t)XRT_TILE;
-
-                // advance the source heads by 512 words (three phases, shared barriers)
-                for (uint32_t done = 0; done < 512u; done += 227u) {
+        // One generation step: every head (and the stream head) that has fewer
+        // than 512 words ready extends its window by at most 227 words.  Steps
+        // must be separated by a barrier; they are placed in front of barriers
+        // the tile needs anyway.  Returns whether anything is still short.
+        auto mt_step = [&]() {
+            int h = 0;
 #pragma unroll
-                    for (int k = 0; k < 6; k++) {
-                        if (head_of[k] >= 0) {
-                            uint64_t want = h_next[k] + 512ull;
-                            uint32_t need = want > h_gen[k] ? (uint32_t)(want - h_gen[k]) : 0u;
-                            if (need > done) {
-                                uint32_t chunk = need - done;
-                                if (chunk > 227u) chunk = 227u;
-                                if ((uint32_t)tid < chunk) {
-                                    uint32_t* r = rings + head_of[k] * XRT_RING;
-                                    uint32_t n = (uint32_t)h_gen[k] + done + (uint32_t)tid;
-                                    r[n & XRT_RMASK] = mt_mix(r[(n - 624u) & XRT_RMASK], r[(n - 623u) & XRT_RMASK],
-                                                              r[(n - 227u) & XRT_RMASK]);
-                                }
-                            }
+            for (int k = 0; k < 6; k++) {
+                if ((S.array_used >> k) & 1u) {
+                    uint32_t avail = hgen[k] - hpos[k];
+                    if (avail < 512u) {
+                        uint32_t chunk = 512u - avail;
+                        if (chunk > 227u) chunk = 227u;
+                        if ((uint32_t)tid < chunk) {
+                            uint32_t* r = rings + h * XRT_RING;
+                            uint32_t n = hgen[k] + (uint32_t)tid;
+                            r[n & XRT_RMASK] = mt_mix(r[(n - 624u) & XRT_RMASK], r[(n - 623u) & XRT_RMASK],
+                                                      r[(n - 227u) & XRT_RMASK]);
                         }
+                        hgen[k] += chunk;
                     }
-                    __syncthreads();
+                    h++;
                 }
-                double u[6];
+            }
+            uint32_t avail = sgen - spos;
+            if (avail < 512u) {
+                uint32_t chunk = 512u - avail;
+                if (chunk > 227u) chunk = 227u;
+                if ((uint32_t)tid < chunk) {
+                    uint32_t n = sgen + (uint32_t)tid;
+                    stream[n & XRT_RMASK] = mt_mix(stream[(n - 624u) & XRT_RMASK], stream[(n - 623u) & XRT_RMASK],
+                                                   stream[(n - 227u) & XRT_RMASK]);
+                }
+                sgen += chunk;
+            }
+        };
+        auto mt_short = [&]() -> bool {
+            bool s = (sgen - spos) < 512u;
+#pragma unroll
+            for (int k = 0; k < 6; k++)
+                if ((S.array_used >> k) & 1u) s = s || ((hgen[k] - hpos[k]) < 512u);
+            return s;
+        };
+
+        // ---- tiles of 256 rays in original order ----------------------------
+        for (int64_t i0 = 0; i0 < N; i0 += XRT_TILE) {
+            const int64_t left = N - i0;
+            uint32_t n_in = left < XRT_TILE ? (uint32_t)left : (uint32_t)XRT_TILE;
+
+            // everything this tile consumes must be generated: normally already
+            // done behind the previous tile's barriers
+            while (mt_short()) { mt_step(); __syncthreads(); }
+
+            double u[6];
+            {
+                int h = 0;
 #pragma unroll
                 for (int k = 0; k < 6; k++) {
                     u[k] = 0.0;
-                    if (head_of[k] >= 0) {
-                        const uint32_t* r = rings + head_of[k] * XRT_RING;
-                        uint32_t n = (uint32_t)h_next[k] + 2u * (uint32_t)tid;
+                    if ((S.array_used >> k) & 1u) {
+                        const uint32_t* r = rings + h * XRT_RING;
+                        uint32_t n = hpos[k] + 2u * (uint32_t)tid;
                         u[k] = mt_double(r[n & XRT_RMASK], r[(n + 1u) & XRT_RMASK]);
-                        uint64_t want = h_next[k] + 512ull;
-                        if (want > h_gen[k]) h_gen[k] = want;
-                        h_next[k] = want;
+                        hpos[k] += 512u;
+                        h++;
                     }
                 }
+            }
 
-                Ray ray;
-                uint32_t id = (uint32_t)(i0 + tid);
-                bool have = (uint32_t)tid < n_in;
-                source_ray(S, u, ray);
-                if (tid == 0) cnt[0] += n_in;
-                if (HIST && have) hist_write(args.hist, args.hmask, N, 0, id, ray.o, ray.d, ray.wl, true);
+            Ray ray;
+            uint32_t id = (uint32_t)(i0 + tid);
+            bool have = (uint32_t)tid < n_in;
+            source_ray<FULL>(S, u, ray);
+            if (tid == 0) cnt[0] += n_in;
+            if (HIST && have) hist_write(args.hist, args.hmask, N, 0, id, ray.o, ray.d, ray.wl, true);
 
-                // ---- optics in config order (objects/_Dispatcher.py:166-196) --
-                for (int e = 0; e < sc.n_optics && n_in > 0; e++) {
-                    const KOptic& op = sc.opt[e];
-                    V3 X, nrm;
-                    X.x = X.y = X.z = 0.0; nrm = X;
-                    bool alive = false;
-                    if (have) {
-                        bool hit = intersect(op, ray, X, nrm);
-                        alive = hit && check_bounds(op, X);
-                        if (HIST && !alive) {
-                            V3 xo = X;
-                            if (!hit) { xo.x = xo.y = xo.z = __builtin_nan(""); }
-                            hist_write(args.hist, args.hmask, N, e + 1, id, xo, ray.d, ray.wl, false);
-                        }
+            // ---- optics in config order (objects/_Dispatcher.py:166-196) ------
+            for (int e = 0; e < sc.n_optics && n_in > 0; e++) {
+                const KOptic& op = sc.opt[e];
+                V3 X, nrm;
+                X.x = X.y = X.z = 0.0; nrm = X;
+                bool alive = false;
+                if (have) {
+                    bool hit = intersect<FULL>(op, ray, X, nrm);
+                    alive = hit && check_bounds<FULL>(op, X);
+                    if (HIST && !alive) {
+                        V3 xo = X;
+                        if (!hit) { xo.x = xo.y = xo.z = __builtin_nan(""); }
+                        hist_write(args.hist, args.hmask, N, e + 1, id, xo, ray.d, ray.wl, false);
                     }
-                    const bool bragg = (op.interact == XRT_INTERACT_CRYSTAL) && (op.flags & XRT_F_CHECK_BRAGG);
-                    if (bragg) {
-                        // ordered live rank -> index of the ray's uniform in the stream
-                        uint32_t n_a;
-                        uint32_t rank = wg_rank(alive, wave_tot, slot, tid, n_a);
-                        if (alive) {
-                            tile[0 * XRT_TILE + rank] = X.x;     tile[1 * XRT_TILE + rank] = X.y;     tile[2 * XRT_TILE + rank] = X.z;
-                            tile[3 * XRT_TILE + rank] = ray.d.x; tile[4 * XRT_TILE + rank] = ray.d.y; tile[5 * XRT_TILE + rank] = ray.d.z;
-                            tile[6 * XRT_TILE + rank] = ray.wl;
-                            tile[7 * XRT_TILE + rank] = nrm.x;   tile[8 * XRT_TILE + rank] = nrm.y;   tile[9 * XRT_TILE + rank] = nrm.z;
-                            tileid[rank] = id;
-                        }
-                        // n_a uniforms from the stream head (np.random.uniform(0,1,n_live), :189)
-                        {
-                            uint64_t want = s_next + 2ull * n_a;
-                            uint32_t need = want > s_gen ? (uint32_t)(want - s_gen) : 0u;
-                            ring_advance(stream, s_gen, need, tid);     // ends with a barrier when need > 0
-                            if (need == 0) __syncthreads();
-                            s_gen += need;
-                        }
-                        have = (uint32_t)tid < n_a;
-                        alive = false;
-                        if (have) {
-                            X.x = tile[0 * XRT_TILE + tid];     X.y = tile[1 * XRT_TILE + tid];     X.z = tile[2 * XRT_TILE + tid];
-                            ray.d.x = tile[3 * XRT_TILE + tid]; ray.d.y = tile[4 * XRT_TILE + tid]; ray.d.z = tile[5 * XRT_TILE + tid];
-                            ray.wl = tile[6 * XRT_TILE + tid];
-                            nrm.x = tile[7 * XRT_TILE + tid];   nrm.y = tile[8 * XRT_TILE + tid];   nrm.z = tile[9 * XRT_TILE + tid];
-                            id = tileid[tid];
-                            uint32_t n = (uint32_t)s_next + 2u * (uint32_t)tid;
-                            double test = 0.0 + (1.0 - 0.0) * mt_double(stream[n & XRT_RMASK], stream[(n + 1u) & XRT_RMASK]);
-                            alive = bragg_accept(op, ray, nrm, test);
-                            if (HIST && !alive) hist_write(args.hist, args.hmask, N, e + 1, id, X, ray.d, ray.wl, false);
-                        }
-                        s_next += 2ull * n_a;
-                    }
-                    // InteractObject / InteractMirror.reflect_vectors (optics/_InteractMirror.py:29-42)
+                }
+                const bool bragg = (op.interact == XRT_INTERACT_CRYSTAL) && (op.flags & XRT_F_CHECK_BRAGG);
+                if (bragg) {
+                    // ordered live rank -> index of the ray's uniform in the stream
+                    uint32_t n_a;
+                    mt_step();
+                    uint32_t rank = wg_rank(alive, wave_tot, slot, tid, n_a);
                     if (alive) {
-                        ray.o = X;
-                        if (op.interact != XRT_INTERACT_NONE) {
-                            double dt = dot_e(ray.d, nrm);
-                            ray.d.x = ray.d.x - 2.0 * (dt * nrm.x);
-                            ray.d.y = ray.d.y - 2.0 * (dt * nrm.y);
-                            ray.d.z = ray.d.z - 2.0 * (dt * nrm.z);
-                        }
-                        if ((op.flags & XRT_F_IMAGE) && args.images) image_hit(op, X, args.images);
-                        if (HIST) hist_write(args.hist, args.hmask, N, e + 1, id, ray.o, ray.d, ray.wl, true);
+                        tile[0 * XRT_TILE + rank] = X.x;     tile[1 * XRT_TILE + rank] = X.y;     tile[2 * XRT_TILE + rank] = X.z;
+                        tile[3 * XRT_TILE + rank] = ray.d.x; tile[4 * XRT_TILE + rank] = ray.d.y; tile[5 * XRT_TILE + rank] = ray.d.z;
+                        tile[6 * XRT_TILE + rank] = ray.wl;
+                        tile[7 * XRT_TILE + rank] = nrm.x;   tile[8 * XRT_TILE + rank] = nrm.y;   tile[9 * XRT_TILE + rank] = nrm.z;
+                        tileid[rank] = id;
                     }
-                    // stable compaction of the survivors for the next element
-                    uint32_t n_out;
-                    uint32_t rank = wg_rank(alive, wave_tot, slot, tid, n_out);
-                    if (tid == 0) cnt[e + 1] += n_out;
-                    if (e + 1 < sc.n_optics && n_out > 0) {
-                        if (alive) {
-                            tile[0 * XRT_TILE + rank] = ray.o.x; tile[1 * XRT_TILE + rank] = ray.o.y; tile[2 * XRT_TILE + rank] = ray.o.z;
-                            tile[3 * XRT_TILE + rank] = ray.d.x; tile[4 * XRT_TILE + rank] = ray.d.y; tile[5 * XRT_TILE + rank] = ray.d.z;
-                            tile[6 * XRT_TILE + rank] = ray.wl;
-                            tileid[rank] = id;
-                        }
-                        __syncthreads();
-                        have = (uint32_t)tid < n_out;
-                        if (have) {
-                            ray.o.x = tile[0 * XRT_TILE + tid]; ray.o.y = tile[1 * XRT_TILE + tid]; ray.o.z = tile[2 * XRT_TILE + tid];
-                            ray.d.x = tile[3 * XRT_TILE + tid]; ray.d.y = tile[4 * XRT_TILE + tid]; ray.d.z = tile[5 * XRT_TILE + tid];
-                            ray.wl = tile[6 * XRT_TILE + tid];
-                            id = tileid[tid];
-                        }
-                        __syncthreads();
+                    mt_step();
+                    __syncthreads();
+                    have = (uint32_t)tid < n_a;
+                    alive = false;
+                    if (have) {
+                        X.x = tile[0 * XRT_TILE + tid];     X.y = tile[1 * XRT_TILE + tid];     X.z = tile[2 * XRT_TILE + tid];
+                        ray.d.x = tile[3 * XRT_TILE + tid]; ray.d.y = tile[4 * XRT_TILE + tid]; ray.d.z = tile[5 * XRT_TILE + tid];
+                        ray.wl = tile[6 * XRT_TILE + tid];
+                        nrm.x = tile[7 * XRT_TILE + tid];   nrm.y = tile[8 * XRT_TILE + tid];   nrm.z = tile[9 * XRT_TILE + tid];
+                        id = tileid[tid];
+                        // np.random.uniform(0, 1, n_live)[rank] (optics/_InteractCrystal.py:189)
+                        uint32_t n = spos + 2u * (uint32_t)tid;
+                        double test = 0.0 + (1.0 - 0.0) * mt_double(stream[n & XRT_RMASK], stream[(n + 1u) & XRT_RMASK]);
+                        alive = bragg_accept(op, ray, nrm, test);
+                        if (HIST && !alive) hist_write(args.hist, args.hmask, N, e + 1, id, X, ray.d, ray.wl, false);
                     }
-                    n_in = n_out;
+                    spos += 2u * n_a;
+                    s_used += 2ull * n_a;
                 }
+                // InteractObject / InteractMirror.reflect_vectors (optics/_InteractMirror.py:29-42)
+                if (alive) {
+                    ray.o = X;
+                    if (op.interact != XRT_INTERACT_NONE) {
+                        double dt = dot_e(ray.d, nrm);
+                        ray.d.x = ray.d.x - 2.0 * (dt * nrm.x);
+                        ray.d.y = ray.d.y - 2.0 * (dt * nrm.y);
+                        ray.d.z = ray.d.z - 2.0 * (dt * nrm.z);
+                    }
+                    if ((op.flags & XRT_F_IMAGE) && args.images) image_hit(op, X, args.images);
+                    if (HIST) hist_write(args.hist, args.hmask, N, e + 1, id, ray.o, ray.d, ray.wl, true);
+                }
+                // stable compaction of the survivors for the next element
+                uint32_t n_out;
+                mt_step();
+                uint32_t rank = wg_rank(alive, wave_tot, slot, tid, n_out);
+                if (tid == 0) cnt[e + 1] += n_out;
+                if (e + 1 < sc.n_optics && n_out > 0) {
+                    if (alive) {
+                        tile[0 * XRT_TILE + rank] = ray.o.x; tile[1 * XRT_TILE + rank] = ray.o.y; tile[2 * XRT_TILE + rank] = ray.o.z;
+                        tile[3 * XRT_TILE + rank] = ray.d.x; tile[4 * XRT_TILE + rank] = ray.d.y; tile[5 * XRT_TILE + rank] = ray.d.z;
+                        tile[6 * XRT_TILE + rank] = ray.wl;
+                        tileid[rank] = id;
+                    }
+                    mt_step();
+                    __syncthreads();
+                    have = (uint32_t)tid < n_out;
+                    if (have) {
+                        ray.o.x = tile[0 * XRT_TILE + tid]; ray.o.y = tile[1 * XRT_TILE + tid]; ray.o.z = tile[2 * XRT_TILE + tid];
+                        ray.d.x = tile[3 * XRT_TILE + tid]; ray.d.y = tile[4 * XRT_TILE + tid]; ray.d.z = tile[5 * XRT_TILE + tid];
+                        ray.wl = tile[6 * XRT_TILE + tid];
+                        id = tileid[tid];
+                    }
+                    // the next write to the tile happens behind the next scan's barrier
+                }
+                n_in = n_out;
             }
         }
 
-        // ---- run done: counters out, optional final generator state ---------
+        // ---- run done: counters out, stream head back to memory ---------------
         __syncthreads();
         if (tid <= sc.n_optics && cnt[tid] != 0ULL) atomicAdd(&args.num_out[tid], cnt[tid]);
-        if (HIST && args.state_out) {
-            // numpy state: key = the 624-word block containing s_next, pos = offset in it
-            uint64_t block = (s_next == 0) ? 0 : ((s_next - 1) / 624ull) * 624ull;
-            uint64_t want = block + 624ull;
-            while (s_gen < want) {
-                uint64_t rem = want - s_gen;
-                uint32_t m = rem > 400ull ? 400u : (uint32_t)rem;
-                ring_advance(stream, s_gen, m, tid);
-                s_gen += m;
-            }
-            __syncthreads();
-            for (int i = tid; i < 624; i += XRT_TILE)
-                args.state_out->key[i] = stream[((uint32_t)block + (uint32_t)i) & XRT_RMASK];
-            if (tid == 0) {
-                args.state_out->pos = (int32_t)(s_next - block);
-                args.state_out->has_gauss = st->has_gauss;
-                args.state_out->gauss = st->gauss;
-            }
+        for (int i = tid; i < (int)XRT_RING; i += XRT_TILE) st->ring[i] = stream[i];
+        if (tid == 0) {
+            st->next = s_next0 + s_used;
+            st->gen = s_gen0 + (uint64_t)(uint32_t)(sgen - (uint32_t)s_gen0);
         }
         __syncthreads();
     }
-}
-
-// np.random.seed(int) -> init_genrand, one thread per run (xicsrt_raytrace.py:111)
-__global__ void xrt_seed_kernel(const uint32_t* seeds, KState* states, int n_runs)
-{
-    int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_runs) return;
-    uint32_t s = seeds[r];
-    KState* st = states + r;
-    for (int i = 0; i < 624; i++) {
-        st->key[i] = s;
-        s = 1812433253u * (s ^ (s >> 30)) + (uint32_t)(i + 1);
-    }
-    st->pos = 624;
-    st->has_gauss = 0;
-    st->gauss = 0.0;
 }
 
 // ==========================================================================
@@ -807,19 +924,42 @@ extern "C" int xrt_scene_check(const xrt_scene_t* sc)
     return 0;
 }
 
-// workspace layout: [run counter 256 B][apertures][voigt tables][states]
+// workspace layout: [run counter 256 B][apertures][voigt tables][KState in][seeds][streams][heads]
+static int count_heads(const xrt_scene_t* sc)
+{
+    int n = 2;      // the two angular arrays are always needed
+    for (int i = 0; i < 3; i++) if (sc->source.size[i] != 0.0) n++;
+    if (sc->source.wavelength_dist == XRT_WL_UNIFORM || sc->source.wavelength_dist == XRT_WL_VOIGT) n++;
+    return n;
+}
+static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 static size_t ws_off_apertures() { return 256; }
 static size_t ws_off_voigt() { return ws_off_apertures() + sizeof(xrt_aperture_t) * XRT_MAX_APERTURES * XRT_DEV_MAX_OPTICS; }
-static size_t ws_off_states(const xrt_scene_t* sc)
+static size_t ws_off_state(const xrt_scene_t* sc)
 {
-    size_t v = ws_off_voigt() + 2 * sizeof(double) * (size_t)(sc->source.voigt_n > 0 ? sc->source.voigt_n : 0);
-    return (v + 255) & ~(size_t)255;
+    return al256(ws_off_voigt() + 2 * sizeof(double) * (size_t)(sc->source.voigt_n > 0 ? sc->source.voigt_n : 0));
 }
+static size_t ws_off_seeds(const xrt_scene_t* sc) { return al256(ws_off_state(sc) + sizeof(KState)); }
+static size_t ws_off_streams(const xrt_scene_t* sc, int n_runs) { return al256(ws_off_seeds(sc) + sizeof(uint32_t) * (size_t)n_runs); }
+static size_t ws_off_heads(const xrt_scene_t* sc, int n_runs) { return al256(ws_off_streams(sc, n_runs) + sizeof(KStream) * (size_t)n_runs); }
 
 extern "C" size_t xrt_workspace_bytes(const xrt_scene_t* sc, int32_t n_runs)
 {
     if (!sc || n_runs < 0) return 0;
-    return ws_off_states(sc) + sizeof(KState) * (size_t)(n_runs > 0 ? n_runs : 1) + sizeof(uint32_t) * (size_t)(n_runs > 0 ? n_runs : 1) + 256;
+    if (n_runs < 1) n_runs = 1;
+    return ws_off_heads(sc, n_runs) + sizeof(KStream) * (size_t)n_runs * (size_t)count_heads(sc) + 256;
+}
+
+static bool needs_full(const xrt_scene_t* sc)
+{
+    const xrt_source_t& s = sc->source;
+    if (s.kind == XRT_SRC_FOCUSED || s.angular_dist != XRT_ANG_ISOTROPIC || s.wavelength_dist == XRT_WL_VOIGT) return true;
+    for (int e = 0; e < sc->n_optics; e++) {
+        const xrt_optic_t& o = sc->optics[e];
+        if (o.shape == XRT_SHAPE_CYLINDER) return true;
+        if ((o.flags & XRT_F_CHECK_APERTURE) && o.n_apertures > 0) return true;
+    }
+    return false;
 }
 
 static void build_kscene(const xrt_scene_t* sc, char* ws, KScene* k)
@@ -869,25 +1009,17 @@ static void build_kscene(const xrt_scene_t* sc, char* ws, KScene* k)
     }
 }
 
-static size_t lds_bytes(const KScene& k)
+static size_t lds_bytes(int n_src_heads)
 {
-    int heads = 1;
-    for (int i = 0; i < k.src.n_arrays; i++) if ((k.src.array_used >> i) & 1u) heads++;
     size_t b = sizeof(double) * XRT_TILE_COMP * XRT_TILE + sizeof(uint32_t) * XRT_TILE;
-    b += sizeof(uint32_t) * XRT_RING * (size_t)heads;
+    b += sizeof(uint32_t) * XRT_RING * (size_t)(n_src_heads + 1);
     b += sizeof(uint32_t) * (8 + 2 * (XRT_DEV_MAX_OPTICS + 2) + 8);
     return (b + 15) & ~(size_t)15;
 }
 
-template <bool HIST>
-static int launch(const xrt_scene_t* sc, char* ws, const KArgs& a_in, int n_runs, hipStream_t stream)
+// uploads of the small tables (pageable host memory -> staged copies, ordered on the stream)
+static int upload_tables(const xrt_scene_t* sc, char* ws, hipStream_t stream)
 {
-    KScene ks;
-    build_kscene(sc, ws, &ks);
-    KArgs a = a_in;
-    a.run_counter = reinterpret_cast<uint32_t*>(ws);
-    HIP_TRY(hipMemsetAsync(ws, 0, 256, stream));
-    // apertures and voigt tables: pageable host memory -> staged copies, ordered on the stream
     for (int e = 0; e < sc->n_optics; e++)
         if (sc->optics[e].n_apertures > 0)
             HIP_TRY(hipMemcpyAsync(ws + ws_off_apertures() + sizeof(xrt_aperture_t) * XRT_MAX_APERTURES * (size_t)e,
@@ -898,8 +1030,13 @@ static int launch(const xrt_scene_t* sc, char* ws, const KArgs& a_in, int n_runs
         HIP_TRY(hipMemcpyAsync(ws + ws_off_voigt(), sc->source.voigt_cdf, nb, hipMemcpyHostToDevice, stream));
         HIP_TRY(hipMemcpyAsync(ws + ws_off_voigt() + nb, sc->source.voigt_x, nb, hipMemcpyHostToDevice, stream));
     }
-    const size_t lds = lds_bytes(ks);
-    auto kern = xrt_trace_kernel<HIST>;
+    return 0;
+}
+
+template <bool HIST, bool FULL>
+static int launch_variant(const KScene& ks, const KArgs& a, int n_runs, size_t lds, hipStream_t stream)
+{
+    auto kern = xrt_trace_kernel<HIST, FULL>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int dev = 0, cus = 256, per_cu = 1;
     HIP_TRY(hipGetDevice(&dev));
@@ -923,6 +1060,24 @@ static int launch(const xrt_scene_t* sc, char* ws, const KArgs& a_in, int n_runs
     return 0;
 }
 
+// one iteration of every run: position the heads, then propagate
+static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArgs a, int n_runs, bool hist, hipStream_t stream)
+{
+    const int nh = count_heads(sc);
+    KStream* streams = reinterpret_cast<KStream*>(ws + ws_off_streams(sc, n_runs));
+    KStream* heads = reinterpret_cast<KStream*>(ws + ws_off_heads(sc, n_runs));
+    hipLaunchKernelGGL(xrt_seek_kernel, dim3((n_runs + 3) / 4), dim3(256), 0, stream,
+                       streams, heads, n_runs, ks.src.n_arrays, ks.src.array_used, nh, ks.src.n_rays);
+    HIP_TRY(hipGetLastError());
+    a.streams = streams; a.heads = heads; a.n_runs = n_runs; a.n_src_heads = nh;
+    a.run_counter = reinterpret_cast<uint32_t*>(ws);
+    HIP_TRY(hipMemsetAsync(ws, 0, 256, stream));
+    const size_t lds = lds_bytes(nh);
+    const bool full = needs_full(sc);
+    if (hist) return full ? launch_variant<true, true>(ks, a, n_runs, lds, stream) : launch_variant<true, false>(ks, a, n_runs, lds, stream);
+    return full ? launch_variant<false, true>(ks, a, n_runs, lds, stream) : launch_variant<false, false>(ks, a, n_runs, lds, stream);
+}
+
 extern "C" int xrt_trace(const xrt_scene_t* sc, const uint32_t* seeds, int32_t n_runs, int32_t n_iter,
                          uint64_t* num_out, uint64_t* images, void* workspace, size_t workspace_bytes, void* stream_)
 {
@@ -933,17 +1088,26 @@ extern "C" int xrt_trace(const xrt_scene_t* sc, const uint32_t* seeds, int32_t n
     if (workspace_bytes < xrt_workspace_bytes(sc, n_runs)) return fail(-4, "%s", "workspace too small");
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     char* ws = reinterpret_cast<char*>(workspace);
-    KState* states = reinterpret_cast<KState*>(ws + ws_off_states(sc));
-    uint32_t* d_seeds = reinterpret_cast<uint32_t*>(states + n_runs);
+    uint32_t* d_seeds = reinterpret_cast<uint32_t*>(ws + ws_off_seeds(sc));
+    KStream* streams = reinterpret_cast<KStream*>(ws + ws_off_streams(sc, n_runs));
     HIP_TRY(hipMemcpyAsync(d_seeds, seeds, sizeof(uint32_t) * (size_t)n_runs, hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(xrt_seed_kernel, dim3((n_runs + 63) / 64), dim3(64), 0, stream, d_seeds, states, n_runs);
+    hipLaunchKernelGGL(xrt_seed_kernel, dim3((n_runs + 63) / 64), dim3(64), 0, stream, d_seeds, streams, n_runs);
     HIP_TRY(hipGetLastError());
+    st = upload_tables(sc, ws, stream);
+    if (st) return st;
+    KScene ks;
+    build_kscene(sc, ws, &ks);
     KArgs a;
     memset(&a, 0, sizeof(a));
-    a.states = states; a.n_runs = n_runs; a.n_iter = n_iter;
     a.num_out = reinterpret_cast<unsigned long long*>(num_out);
     a.images = reinterpret_cast<unsigned long long*>(images);
-    return launch<false>(sc, ws, a, n_runs, stream);
+    // iterations share each run's stream (xicsrt_raytrace.py:153): the stream head left by
+    // iteration i is where iteration i+1 starts
+    for (int it = 0; it < n_iter; it++) {
+        st = run_iteration(sc, ks, ws, a, n_runs, false, stream);
+        if (st) return st;
+    }
+    return 0;
 }
 
 extern "C" int xrt_trace_history(const xrt_scene_t* sc, const xrt_rng_state_t* state_in,
@@ -958,15 +1122,28 @@ extern "C" int xrt_trace_history(const xrt_scene_t* sc, const xrt_rng_state_t* s
     static_assert(sizeof(KState) == sizeof(xrt_rng_state_t), "state layout");
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     char* ws = reinterpret_cast<char*>(workspace);
-    KState* states = reinterpret_cast<KState*>(ws + ws_off_states(sc));
-    HIP_TRY(hipMemcpyAsync(states, state_in, sizeof(KState), hipMemcpyHostToDevice, stream));
+    KState* d_state = reinterpret_cast<KState*>(ws + ws_off_state(sc));
+    KStream* streams = reinterpret_cast<KStream*>(ws + ws_off_streams(sc, 1));
+    HIP_TRY(hipMemcpyAsync(d_state, state_in, sizeof(KState), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(xrt_import_state_kernel, dim3(1), dim3(64), 0, stream, d_state, streams);
+    HIP_TRY(hipGetLastError());
+    st = upload_tables(sc, ws, stream);
+    if (st) return st;
+    KScene ks;
+    build_kscene(sc, ws, &ks);
     KArgs a;
     memset(&a, 0, sizeof(a));
-    a.states = states; a.n_runs = 1; a.n_iter = 1;
     a.num_out = reinterpret_cast<unsigned long long*>(num_out);
     a.images = reinterpret_cast<unsigned long long*>(images);
-    a.hist = rays; a.hmask = mask; a.state_out = reinterpret_cast<KState*>(state_out);
-    return launch<true>(sc, ws, a, 1, stream);
+    a.hist = rays; a.hmask = mask;
+    st = run_iteration(sc, ks, ws, a, 1, true, stream);
+    if (st) return st;
+    if (state_out) {
+        hipLaunchKernelGGL(xrt_export_state_kernel, dim3(1), dim3(64), 0, stream, streams, d_state,
+                           reinterpret_cast<KState*>(state_out));
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
 }
 
 extern "C" int xrt_timing_begin(void)
