@@ -55,7 +55,7 @@ def spectrometer_config(n_rays, n_runs, seed=0):
     }
 
 
-def cpu_baseline(flat, n_rays, target_seconds=15.0):
+def cpu_baseline(flat, n_rays, target_seconds=8.0):
     """Oracle (port of the reference's pool-over-runs path) on the host cores, bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import helpers
@@ -74,6 +74,23 @@ def cpu_baseline(flat, n_rays, target_seconds=15.0):
     return {'value': runs * n_rays / dt / 1e6, 'unit': 'Mphotons/s', 'cores': threads, 'kind': 'port',
             'sample': '%d runs x %d rays of the same scene, %d threads (one run per thread at a time), %.1f s'
                       % (runs, n_rays, threads, dt)}
+
+
+def measured_traffic(rays, runs):
+    """HBM bytes per launch of the propagation kernel from the committed rocprofv3 counter passes
+    (profiles/*.json written by profiles/run_profile.sh for the same workload), newest first."""
+    import glob
+    best = None
+    for fn in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*.json')), reverse=True):
+        try:
+            d = json.load(open(fn))
+            cfg = d.get('bench_fetch', {}).get('config', {})
+            if cfg.get('rays_per_run') == rays and cfg.get('runs_per_gpu') == runs and 'hbm_traffic_bytes_per_launch' in d:
+                best = (d['hbm_traffic_bytes_per_launch'], os.path.relpath(fn, ROOT))
+                break
+        except Exception:
+            continue
+    return best
 
 
 def main():
@@ -168,6 +185,10 @@ def main():
                          'algorithmic_bytes_per_photon': ALGO_BYTES_PER_PHOTON,
                          'photons_per_launch': per_launch_photons},
         }
+        traffic = measured_traffic(args.rays, args.runs)
+        if traffic is not None:
+            line['roofline']['traffic'] = traffic[0]
+            line['roofline']['traffic_source'] = traffic[1]
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(flat, args.rays)
         print(json.dumps(line))

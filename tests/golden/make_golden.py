@@ -356,7 +356,31 @@ def run_counts(cfg):
     return out
 
 
+def dump_class_defaults():
+    """default_config() of every built-in element class and of the general section (the config contract)."""
+    import glob
+    out = {'general': _jsonable({k: v for k, v in xicsrt_config.default_config()['general'].items()
+                                 if k != 'pathlist_default'})}
+    base = os.path.join(REFERENCE, 'xicsrt')
+    for section in ('sources', 'optics'):
+        out[section] = {}
+        for path in sorted(glob.glob(os.path.join(base, section, '_Xicsrt*.py'))):
+            name = os.path.splitext(os.path.basename(path))[0][1:]
+            try:
+                disp = Dispatcher({'general': xicsrt_config.default_config()['general'],
+                                   section: {'x': {'class_name': name}}}, section)
+                disp.instantiate()
+                out[section][name] = _jsonable(disp.objects['x'].default_config())
+            except Exception as e:
+                out[section][name] = {'__error__': '%s: %s' % (type(e).__name__, e)}
+    json.dump(out, open(os.path.join(HERE, 'class_defaults.json'), 'w'), indent=1, sort_keys=True)
+    print('class_defaults.json:', {k: len(v) for k, v in out.items()})
+
+
 def main(argv):
+    if argv[1:] == ['class_defaults']:
+        dump_class_defaults()
+        return
     cases = build_cases()
     want = argv[1:] or list(cases)
     index = {}

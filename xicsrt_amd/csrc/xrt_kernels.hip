@@ -158,7 +158,7 @@ __device__ __forceinline__ void ring_advance(uint32_t* r, uint64_t gen, uint32_t
 }
 
 // --------------------------------------------------------------------------
-// 3-vector helpers in NumPy's evaluation order (see oracle/xrt_oracle.c header)
+// 3-vector helpers in NumPy's evaluation order (measured on numpy 2.2.6)
 // --------------------------------------------------------------------------
 
 struct V3 { double x, y, z; };

@@ -182,6 +182,16 @@ def shard_runs(num_runs, rank, world):
     return list(range(rank, num_runs, world))
 
 
+def pack_counts(num_out, images):
+    """One integer vector [num_out | image bins] so that the exchange step is a single all-reduce."""
+    import torch
+    return torch.cat([num_out.reshape(-1), images.reshape(-1)])
+
+
+def unpack_counts(packed, n_elements):
+    return packed[:n_elements], packed[n_elements:]
+
+
 def rng_state_from_seed(seed):
     """init_genrand state as np.random.seed(seed) leaves it (key[624], pos=624, no cached gauss)."""
     st = np.random.RandomState(_check_seed(int(seed))).get_state()
@@ -491,11 +501,10 @@ def raytrace(config):
 
     t = device.torch
     if dist is not None and world > 1:
-        packed = t.cat([device.num_out, device.images])
+        packed = pack_counts(device.num_out, device.images)
         dist.all_reduce(packed, op=dist.ReduceOp.SUM)
-        num_out = packed[:device.num_out.numel()].cpu().numpy()
-        images = packed[device.num_out.numel():].cpu().numpy()
-        meta, image = device.unpack(num_out, images)
+        num_out, images = unpack_counts(packed, device.num_out.numel())
+        meta, image = device.unpack(num_out.cpu().numpy(), images.cpu().numpy())
     else:
         meta, image = device.results()
 
