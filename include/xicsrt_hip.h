@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define XRT_ABI_VERSION 4
+#define XRT_ABI_VERSION 5
 
 #define XRT_MAX_OPTICS     16
 #define XRT_MAX_APERTURES  8
@@ -231,6 +231,13 @@ int xrt_trace_history(const xrt_scene_t* scene, const xrt_rng_state_t* state_in,
                       double* rays, uint8_t* mask, void* state_out,
                       void* workspace, size_t workspace_bytes,
                       void* stream);
+
+/* Diagnostic, host only: the MT19937 jump-ahead polynomial g(t) = t^J mod phi(t)
+ * (phi = characteristic polynomial of the generator, degree 19937) that positions
+ * the per-array generator heads: out624 receives 624 words, bit j of word j/32 = g_j,
+ * such that state_word[n + J] = XOR over {j : g_j = 1} of state_word[n + j].
+ * Replaces nothing in the reference (np.random walks its stream sequentially). */
+int xrt_mt_jump_poly(uint64_t J, uint32_t* out624);
 
 /* Name and average duration (ms) bookkeeping of the propagation kernel for the
  * benchmark: brackets the kernel launches of the next xrt_trace calls with HIP

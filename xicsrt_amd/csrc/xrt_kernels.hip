@@ -32,6 +32,7 @@
 #include <string.h>
 #include <stdio.h>
 #include <math.h>
+#include <stdlib.h>
 
 #include "../../include/xicsrt_hip.h"
 
@@ -40,7 +41,9 @@
 #define XRT_RING     1024u
 #define XRT_RMASK    1023u
 #define XRT_MAX_HEADS 7         // 6 source arrays + the stream head
-#define XRT_TILE_COMP 10        // x,y,z, dx,dy,dz, wavelength, nx,ny,nz
+#define XRT_AHEAD    512u       // words every head keeps generated ahead of its read position
+#define XRT_STRETCH  20560      // 19937 + 623 words: what one jump reads
+#define XRT_TILE_COMP 7         // x,y,z, dx,dy,dz, wavelength
 
 // --------------------------------------------------------------------------
 // kernel-argument scene (passed by value: uniform, read through scalar loads)
@@ -210,6 +213,44 @@ __device__ double np_interp(double x, const double* xp, const double* fp, int n)
     return r;
 }
 
+// sin and cos of x in [0, 2*pi] (the cone azimuth).  Quadrant reduction with the
+// two-piece split of pi/2 and the minimax kernels of Sun's fdlibm (k_sin.c, k_cos.c,
+// e_rem_pio2.c medium path; < 1 ulp), evaluated with fused multiply-adds.  The
+// general library routine spends most of its instructions on ranges this path
+// never sees.
+__device__ __forceinline__ void sincos_0_2pi(double x, double* sn, double* cs)
+{
+    const double invpio2 = 6.36619772367581382433e-01;
+    const double pio2_1 = 1.57079632673412561417e+00, pio2_1t = 6.07710050650619224932e-11;
+    const double fn = rint(x * invpio2);
+    const int n = (int)fn;
+    const double r = fma(-fn, pio2_1, x);       // exact: pio2_1 has 33 significant bits
+    const double w = fn * pio2_1t;
+    const double y0 = r - w;
+    const double y1 = (r - y0) - w;
+    const double z = y0 * y0;
+    // k_sin
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double v = z * y0;
+    const double rs = fma(z, fma(z, fma(z, fma(z, S6, S5), S4), S3), S2);
+    const double sv = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * S1);
+    // k_cos
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double rc = z * fma(z, fma(z, fma(z, fma(z, fma(z, C6, C5), C4), C3), C2), C1);
+    const int ix = __double2hiint(y0) & 0x7fffffff;
+    double qx = (ix > 0x3fe90000) ? 0.28125 : __hiloint2double(ix - 0x00200000, 0);
+    if (ix < 0x3fd33333) qx = 0.0;
+    const double hz = 0.5 * z - qx;
+    const double a = 1.0 - qx;
+    const double cv = a - (hz - (z * rc - y0 * y1));
+    const double so = (n & 1) ? cv : sv;
+    const double co = (n & 1) ? sv : cv;
+    *sn = (n & 2) ? -so : so;
+    *cs = ((n + 1) & 2) ? -co : co;
+}
+
 // --------------------------------------------------------------------------
 // source: XicsrtSourceGeneric.generate_rays (sources/_XicsrtSourceGeneric.py:198-227)
 // --------------------------------------------------------------------------
@@ -255,7 +296,7 @@ __device__ __forceinline__ void source_ray(const KSource& s, const double* u, Ra
         double phi = 0.0 + (s.two_pi - 0.0) * u[4];
         double st = sqrt(1.0 - z * z);
         double sn, cs;
-        sincos(phi, &sn, &cs);
+        sincos_0_2pi(phi, &sn, &cs);
         l0 = st * cs; l1 = st * sn; l2 = z;
     } else if (s.angular_dist == XRT_ANG_FLAT) {
         double r = sqrt(0.0 + (s.ang[0] - 0.0) * u[3]);
@@ -301,25 +342,21 @@ __device__ __forceinline__ void source_ray(const KSource& s, const double* u, Ra
 // optics
 // --------------------------------------------------------------------------
 
-// Shape*.intersect: distance, location, normal.  Returns false when the ray has
-// no intersection (mask &= ... in the reference).
+// Shape*.intersect_distance + location_from_distance: the intersection point.
+// Returns false when the ray has no intersection (mask &= ... in the reference).
 template <bool FULL>
-__device__ __forceinline__ bool intersect(const KOptic& op, const Ray& ray, V3& X, V3& nrm)
+__device__ __forceinline__ bool intersect_point(const KOptic& op, const Ray& ray, V3& X)
 {
     double t;
     if (op.shape == XRT_SHAPE_PLANE) {
-        // optics/_ShapePlane.py:32-62 (np.dot -> OpenBLAS dgemv fused order)
+        // optics/_ShapePlane.py:32-52 (np.dot -> OpenBLAS dgemv fused order)
         V3 za = ld3(op.R + 6);
         V3 v = sub3(ld3(op.origin), ray.o);
         t = dot_blas(v, za) / dot_blas(ray.d, za);
         if (!(t >= 0.0)) return false;
-        nrm = za;
-        X.x = ray.o.x + ray.d.x * t; X.y = ray.o.y + ray.d.y * t; X.z = ray.o.z + ray.d.z * t;
-        return true;
     } else if (!FULL || op.shape == XRT_SHAPE_SPHERE) {
-        // optics/_ShapeSphere.py:52-106
-        V3 c = ld3(op.center);
-        V3 L = sub3(c, ray.o);
+        // optics/_ShapeSphere.py:52-100
+        V3 L = sub3(ld3(op.center), ray.o);
         double t_ca = dot_e(L, ray.d);
         double dd = sqrt(dot_e(L, L) - t_ca * t_ca);
         if (!(dd <= op.radius)) return false;
@@ -327,13 +364,8 @@ __device__ __forceinline__ bool intersect(const KOptic& op, const Ray& ray, V3& 
         double t0 = t_ca - t_hc, t1 = t_ca + t_hc;
         if (op.flags & XRT_F_CONVEX) t = (t0 < t1) ? t0 : t1;
         else                         t = (t0 > t1) ? t0 : t1;
-        X.x = ray.o.x + ray.d.x * t; X.y = ray.o.y + ray.d.y * t; X.z = ray.o.z + ray.d.z * t;
-        V3 q = sub3(c, X);
-        double m = norm3(q);
-        nrm.x = q.x / m; nrm.y = q.y / m; nrm.z = q.z / m;
-        return true;
     } else {
-        // optics/_ShapeCylinder.py:52-133
+        // optics/_ShapeCylinder.py:52-110
         V3 pa = ld3(op.center), va = ld3(op.R + 0);
         V3 dp = sub3(ray.o, pa);
         double dDva = dot_e(ray.d, va), dpva = dot_e(dp, va);
@@ -349,15 +381,34 @@ __device__ __forceinline__ bool intersect(const KOptic& op, const Ray& ray, V3& 
         double t0 = (-B - sq) / (2.0 * A), t1 = (-B + sq) / (2.0 * A);
         if (op.flags & XRT_F_CONVEX) t = (t0 < t1) ? t0 : t1;
         else                         t = (t0 > t1) ? t0 : t1;
-        X.x = ray.o.x + ray.d.x * t; X.y = ray.o.y + ray.d.y * t; X.z = ray.o.z + ray.d.z * t;
+    }
+    // ShapeObject.location_from_distance (optics/_ShapeObject.py:79)
+    X.x = ray.o.x + ray.d.x * t; X.y = ray.o.y + ray.d.y * t; X.z = ray.o.z + ray.d.z * t;
+    return true;
+}
+
+// Shape*.intersect_normal at an intersection point (only needed for rays that
+// reflect, so it runs after the bounds test / compaction)
+template <bool FULL>
+__device__ __forceinline__ V3 surface_normal(const KOptic& op, const V3& X)
+{
+    V3 nrm;
+    if (op.shape == XRT_SHAPE_PLANE) {
+        nrm = ld3(op.R + 6);                        // optics/_ShapePlane.py:56-62
+    } else if (!FULL || op.shape == XRT_SHAPE_SPHERE) {
+        V3 q = sub3(ld3(op.center), X);             // optics/_ShapeSphere.py:102-106
+        double m = norm3(q);
+        nrm.x = q.x / m; nrm.y = q.y / m; nrm.z = q.z / m;
+    } else {
+        V3 pa = ld3(op.center), va = ld3(op.R + 0); // optics/_ShapeCylinder.py:112-133
         V3 q = sub3(pa, X);
         double dummy = dot_e(q, va);
         V3 c;
         c.x = (pa.x - dummy * va.x) - X.x; c.y = (pa.y - dummy * va.y) - X.y; c.z = (pa.z - dummy * va.z) - X.z;
         double m = norm3(c);
         nrm.x = c.x / m; nrm.y = c.y / m; nrm.z = c.z / m;
-        return true;
     }
+    return nrm;
 }
 
 // tools/xicsrt_aperture.py:108-204
@@ -419,9 +470,11 @@ __device__ __forceinline__ bool check_bounds(const KOptic& op, const V3& X)
 }
 
 // InteractCrystal.angle_calc + rocking_curve_filter (optics/_InteractCrystal.py:96-196)
-__device__ __forceinline__ bool bragg_accept(const KOptic& op, const Ray& ray, const V3& nrm, double test)
+__device__ __forceinline__ bool bragg_accept(const KOptic& op, const Ray& ray, const V3& nrm, double test,
+                                             bool have_bragg, double bragg_shared)
 {
-    double bragg = asin(ray.wl / op.two_d);
+    // a monochromatic source gives every ray the same asin argument: evaluated once per run
+    double bragg = have_bragg ? bragg_shared : asin(ray.wl / op.two_d);
     V3 neg; neg.x = -1.0 * nrm.x; neg.y = -1.0 * nrm.y; neg.z = -1.0 * nrm.z;
     double dt = fabs(dot_e(ray.d, neg));
     double inc = op.half_pi - acos(dt / norm3(ray.d));
@@ -497,7 +550,12 @@ __global__ void xrt_seed_kernel(const uint32_t* seeds, KStream* streams, int n_r
         st->ring[i] = s;
         s = 1812433253u * (s ^ (s >> 30)) + (uint32_t)(i + 1);
     }
-    st->gen = 624;
+    // canonical form at kernel boundaries: 512 words generated ahead of `next`
+    // (what the propagation kernel leaves behind, and what the jump expects)
+    for (uint32_t n = 624; n < 624u + XRT_AHEAD; n++)
+        st->ring[n & XRT_RMASK] = mt_mix(st->ring[(n - 624u) & XRT_RMASK], st->ring[(n - 623u) & XRT_RMASK],
+                                         st->ring[(n - 227u) & XRT_RMASK]);
+    st->gen = 624 + XRT_AHEAD;
     st->next = 624;
 }
 
@@ -575,6 +633,82 @@ void xrt_seek_kernel(KStream* streams, KStream* heads, int n_runs, int n_arrays,
         for (int i = lane; i < (int)XRT_RING; i += 64) out->ring[i] = ring[i];
         if (lane == 0) { out->gen = gen; out->next = target; }
         if (k < n_arrays) h++;
+    }
+}
+
+// MT19937 jump-ahead (polynomial method, see mt_jump.inc): the window of 624
+// state words J steps ahead is the XOR of the windows at every j with g_j = 1,
+// g(t) = t^J mod phi(t).  One workgroup per run builds the stretch
+// S[i] = s[gen-624+i], i < 19937+623, in LDS once and forms, for every needed
+// source array k and for the stream head, the window that ends at the array's
+// first word (J_k = 2kN - 512 from the canonical stream form gen = next + 512).
+// Cost is independent of N; the sequential xrt_seek_kernel remains the general path.
+#define XRT_JUMP_THREADS 1024
+__global__ __launch_bounds__(XRT_JUMP_THREADS)
+void xrt_jump_kernel(KStream* streams, KStream* heads, const uint32_t* polys, int n_runs, int n_arrays,
+                     uint32_t array_used, int n_src_heads, int n_polys, int64_t n_rays)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t jlds[];
+    uint32_t* S = jlds;                         // [XRT_STRETCH]
+    uint32_t* P = jlds + XRT_STRETCH;           // [n_polys][624]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n_polys * 624; i += XRT_JUMP_THREADS) P[i] = polys[i];
+    for (int run = blockIdx.x; run < n_runs; run += gridDim.x) {
+        KStream* st = streams + run;
+        const uint64_t gen = uni64(st->gen), next = uni64(st->next);
+        __syncthreads();
+        if (tid < 624) S[tid] = st->ring[((uint32_t)gen - 624u + (uint32_t)tid) & XRT_RMASK];
+        __syncthreads();
+        for (int base = 624; base < XRT_STRETCH; base += 227) {
+            int chunk = XRT_STRETCH - base;
+            if (chunk > 227) chunk = 227;
+            if (tid < chunk) {
+                const int n = base + tid;
+                S[n] = mt_mix(S[n - 624], S[n - 623], S[n - 227]);
+            }
+            __syncthreads();
+        }
+        int h = 0, pi = 0;
+        for (int k = 0; k <= n_arrays; k++) {
+            const bool is_stream = (k == n_arrays);
+            if (!is_stream && !((array_used >> k) & 1u)) continue;
+            KStream* out = is_stream ? st : (heads + (size_t)run * n_src_heads + h);
+            const uint64_t target = next + 2ull * (uint64_t)k * (uint64_t)n_rays;
+            if (k == 0) {
+                // the array starts at the stream's own position: plain copy
+                if (tid < (int)XRT_RING) out->ring[tid] = st->ring[tid];
+                if (tid == 0) { out->gen = gen; out->next = next; }
+            } else {
+                const uint32_t* g = P + pi * 624;
+                pi++;
+                if (tid < 624) {        // one output word per thread (waves 0..9)
+                    uint32_t acc = 0;
+                    const uint32_t* sx = S + tid;
+                    for (int b = 0; b < 624; b++) {
+                        uint32_t m = uni32(g[b]);
+                        const uint32_t* base = sx + 32 * b;
+                        // four loads in flight per trip while the mask has that many bits left
+                        while (__builtin_popcount(m) >= 4) {
+                            const int i0 = __builtin_ctz(m); m &= m - 1u;
+                            const int i1 = __builtin_ctz(m); m &= m - 1u;
+                            const int i2 = __builtin_ctz(m); m &= m - 1u;
+                            const int i3 = __builtin_ctz(m); m &= m - 1u;
+                            const uint32_t a0 = base[i0], a1 = base[i1], a2 = base[i2], a3 = base[i3];
+                            acc ^= (a0 ^ a1) ^ (a2 ^ a3);
+                        }
+                        while (m) {
+                            const int i = __builtin_ctz(m);
+                            m &= m - 1u;
+                            acc ^= base[i];
+                        }
+                    }
+                    // window [target-624, target): only these 624 slots of the ring are meaningful
+                    out->ring[((uint32_t)target - 624u + (uint32_t)tid) & XRT_RMASK] = acc;
+                }
+                if (tid == 0) { out->gen = target; out->next = target; }
+            }
+            if (!is_stream) h++;
+        }
     }
 }
 
@@ -719,6 +853,14 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
             return s;
         };
 
+        // Bragg angle shared by all rays when the wavelength is one constant
+        const bool wl_shared = (S.wavelength_dist == XRT_WL_CONST) && !S.has_velocity;
+        double bragg_shared = 0.0;
+        if (wl_shared)
+            for (int e = 0; e < sc.n_optics; e++)
+                if (sc.opt[e].interact == XRT_INTERACT_CRYSTAL && (sc.opt[e].flags & XRT_F_CHECK_BRAGG))
+                    bragg_shared = asin((1.0 * S.wavelength) / sc.opt[e].two_d);
+
         // ---- tiles of 256 rays in original order ----------------------------
         for (int64_t i0 = 0; i0 < N; i0 += XRT_TILE) {
             const int64_t left = N - i0;
@@ -758,7 +900,7 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
                 X.x = X.y = X.z = 0.0; nrm = X;
                 bool alive = false;
                 if (have) {
-                    bool hit = intersect<FULL>(op, ray, X, nrm);
+                    bool hit = intersect_point<FULL>(op, ray, X);
                     alive = hit && check_bounds<FULL>(op, X);
                     if (HIST && !alive) {
                         V3 xo = X;
@@ -776,7 +918,6 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
                         tile[0 * XRT_TILE + rank] = X.x;     tile[1 * XRT_TILE + rank] = X.y;     tile[2 * XRT_TILE + rank] = X.z;
                         tile[3 * XRT_TILE + rank] = ray.d.x; tile[4 * XRT_TILE + rank] = ray.d.y; tile[5 * XRT_TILE + rank] = ray.d.z;
                         tile[6 * XRT_TILE + rank] = ray.wl;
-                        tile[7 * XRT_TILE + rank] = nrm.x;   tile[8 * XRT_TILE + rank] = nrm.y;   tile[9 * XRT_TILE + rank] = nrm.z;
                         tileid[rank] = id;
                     }
                     mt_step();
@@ -787,12 +928,12 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
                         X.x = tile[0 * XRT_TILE + tid];     X.y = tile[1 * XRT_TILE + tid];     X.z = tile[2 * XRT_TILE + tid];
                         ray.d.x = tile[3 * XRT_TILE + tid]; ray.d.y = tile[4 * XRT_TILE + tid]; ray.d.z = tile[5 * XRT_TILE + tid];
                         ray.wl = tile[6 * XRT_TILE + tid];
-                        nrm.x = tile[7 * XRT_TILE + tid];   nrm.y = tile[8 * XRT_TILE + tid];   nrm.z = tile[9 * XRT_TILE + tid];
                         id = tileid[tid];
+                        nrm = surface_normal<FULL>(op, X);
                         // np.random.uniform(0, 1, n_live)[rank] (optics/_InteractCrystal.py:189)
                         uint32_t n = spos + 2u * (uint32_t)tid;
                         double test = 0.0 + (1.0 - 0.0) * mt_double(stream[n & XRT_RMASK], stream[(n + 1u) & XRT_RMASK]);
-                        alive = bragg_accept(op, ray, nrm, test);
+                        alive = bragg_accept(op, ray, nrm, test, wl_shared, bragg_shared);
                         if (HIST && !alive) hist_write(args.hist, args.hmask, N, e + 1, id, X, ray.d, ray.wl, false);
                     }
                     spos += 2u * n_a;
@@ -802,6 +943,7 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
                 if (alive) {
                     ray.o = X;
                     if (op.interact != XRT_INTERACT_NONE) {
+                        if (!bragg) nrm = surface_normal<FULL>(op, X);
                         double dt = dot_e(ray.d, nrm);
                         ray.d.x = ray.d.x - 2.0 * (dt * nrm.x);
                         ray.d.y = ray.d.y - 2.0 * (dt * nrm.y);
@@ -838,7 +980,9 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
         }
 
         // ---- run done: counters out, stream head back to memory ---------------
+        // canonical form: exactly 512 words generated ahead (what xrt_jump_kernel expects)
         __syncthreads();
+        while ((sgen - spos) < XRT_AHEAD) { mt_step(); __syncthreads(); }
         if (tid <= sc.n_optics && cnt[tid] != 0ULL) atomicAdd(&args.num_out[tid], cnt[tid]);
         for (int i = tid; i < (int)XRT_RING; i += XRT_TILE) st->ring[i] = stream[i];
         if (tid == 0) {
@@ -852,6 +996,8 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
 // ==========================================================================
 // host side of the C ABI
 // ==========================================================================
+
+#include "mt_jump.inc"
 
 static thread_local char g_err[512] = "";
 
@@ -942,12 +1088,16 @@ static size_t ws_off_state(const xrt_scene_t* sc)
 static size_t ws_off_seeds(const xrt_scene_t* sc) { return al256(ws_off_state(sc) + sizeof(KState)); }
 static size_t ws_off_streams(const xrt_scene_t* sc, int n_runs) { return al256(ws_off_seeds(sc) + sizeof(uint32_t) * (size_t)n_runs); }
 static size_t ws_off_heads(const xrt_scene_t* sc, int n_runs) { return al256(ws_off_streams(sc, n_runs) + sizeof(KStream) * (size_t)n_runs); }
+static size_t ws_off_polys(const xrt_scene_t* sc, int n_runs)
+{
+    return al256(ws_off_heads(sc, n_runs) + sizeof(KStream) * (size_t)n_runs * (size_t)count_heads(sc));
+}
 
 extern "C" size_t xrt_workspace_bytes(const xrt_scene_t* sc, int32_t n_runs)
 {
     if (!sc || n_runs < 0) return 0;
     if (n_runs < 1) n_runs = 1;
-    return ws_off_heads(sc, n_runs) + sizeof(KStream) * (size_t)n_runs * (size_t)count_heads(sc) + 256;
+    return ws_off_polys(sc, n_runs) + sizeof(uint32_t) * 624 * (XRT_MAX_HEADS + 1) + 256;
 }
 
 static bool needs_full(const xrt_scene_t* sc)
@@ -1060,15 +1210,44 @@ static int launch_variant(const KScene& ks, const KArgs& a, int n_runs, size_t l
     return 0;
 }
 
-// one iteration of every run: position the heads, then propagate
-static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArgs a, int n_runs, bool hist, hipStream_t stream)
+// one iteration of every run: position the heads (jump-ahead when every stream is in the
+// canonical form and the arrays are long enough, else the sequential walk), then propagate
+static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArgs a, int n_runs, bool hist,
+                         bool canonical, hipStream_t stream)
 {
     const int nh = count_heads(sc);
     KStream* streams = reinterpret_cast<KStream*>(ws + ws_off_streams(sc, n_runs));
     KStream* heads = reinterpret_cast<KStream*>(ws + ws_off_heads(sc, n_runs));
-    hipLaunchKernelGGL(xrt_seek_kernel, dim3((n_runs + 3) / 4), dim3(256), 0, stream,
-                       streams, heads, n_runs, ks.src.n_arrays, ks.src.array_used, nh, ks.src.n_rays);
-    HIP_TRY(hipGetLastError());
+    const int64_t N = ks.src.n_rays;
+    static const bool no_jump = getenv("XICSRT_NO_JUMP") != nullptr;
+    if (canonical && !no_jump && N >= (int64_t)XRT_AHEAD / 2) {
+        static thread_local std::vector<uint32_t> hpolys;
+        hpolys.clear();
+        int n_polys = 0;
+        for (int k = 1; k <= ks.src.n_arrays; k++) {
+            if (k < ks.src.n_arrays && !((ks.src.array_used >> k) & 1u)) continue;
+            hpolys.resize((size_t)(n_polys + 1) * 624);
+            const uint64_t J = 2ull * (uint64_t)k * (uint64_t)N - (uint64_t)XRT_AHEAD;
+            if (!mtjump::jump_poly(J, hpolys.data() + (size_t)n_polys * 624))
+                return fail(-5, "%s", "MT19937 characteristic polynomial could not be derived");
+            n_polys++;
+        }
+        uint32_t* d_polys = reinterpret_cast<uint32_t*>(ws + ws_off_polys(sc, n_runs));
+        HIP_TRY(hipMemcpyAsync(d_polys, hpolys.data(), sizeof(uint32_t) * 624 * (size_t)n_polys, hipMemcpyHostToDevice, stream));
+        const size_t jl = sizeof(uint32_t) * ((size_t)XRT_STRETCH + 624 * (size_t)n_polys);
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(xrt_jump_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)jl));
+        int dev = 0, cus = 256;
+        HIP_TRY(hipGetDevice(&dev));
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        int grid = n_runs < cus ? n_runs : cus;
+        hipLaunchKernelGGL(xrt_jump_kernel, dim3(grid), dim3(XRT_JUMP_THREADS), jl, stream, streams, heads, d_polys, n_runs,
+                           ks.src.n_arrays, ks.src.array_used, nh, n_polys, N);
+        HIP_TRY(hipGetLastError());
+    } else {
+        hipLaunchKernelGGL(xrt_seek_kernel, dim3((n_runs + 3) / 4), dim3(256), 0, stream,
+                           streams, heads, n_runs, ks.src.n_arrays, ks.src.array_used, nh, N);
+        HIP_TRY(hipGetLastError());
+    }
     a.streams = streams; a.heads = heads; a.n_runs = n_runs; a.n_src_heads = nh;
     a.run_counter = reinterpret_cast<uint32_t*>(ws);
     HIP_TRY(hipMemsetAsync(ws, 0, 256, stream));
@@ -1076,6 +1255,14 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
     const bool full = needs_full(sc);
     if (hist) return full ? launch_variant<true, true>(ks, a, n_runs, lds, stream) : launch_variant<true, false>(ks, a, n_runs, lds, stream);
     return full ? launch_variant<false, true>(ks, a, n_runs, lds, stream) : launch_variant<false, false>(ks, a, n_runs, lds, stream);
+}
+
+// diagnostic: g(t) = t^J mod phi(t) as 624 words (bit j of word j/32 = g_j); host only
+extern "C" int xrt_mt_jump_poly(uint64_t J, uint32_t* out624)
+{
+    if (!out624) return fail(-1, "%s", "NULL argument");
+    if (!mtjump::jump_poly(J, out624)) return fail(-5, "%s", "MT19937 characteristic polynomial could not be derived");
+    return 0;
 }
 
 extern "C" int xrt_trace(const xrt_scene_t* sc, const uint32_t* seeds, int32_t n_runs, int32_t n_iter,
@@ -1104,7 +1291,7 @@ extern "C" int xrt_trace(const xrt_scene_t* sc, const uint32_t* seeds, int32_t n
     // iterations share each run's stream (xicsrt_raytrace.py:153): the stream head left by
     // iteration i is where iteration i+1 starts
     for (int it = 0; it < n_iter; it++) {
-        st = run_iteration(sc, ks, ws, a, n_runs, false, stream);
+        st = run_iteration(sc, ks, ws, a, n_runs, false, true, stream);
         if (st) return st;
     }
     return 0;
@@ -1136,7 +1323,7 @@ extern "C" int xrt_trace_history(const xrt_scene_t* sc, const xrt_rng_state_t* s
     a.num_out = reinterpret_cast<unsigned long long*>(num_out);
     a.images = reinterpret_cast<unsigned long long*>(images);
     a.hist = rays; a.hmask = mask;
-    st = run_iteration(sc, ks, ws, a, 1, true, stream);
+    st = run_iteration(sc, ks, ws, a, 1, true, false, stream);
     if (st) return st;
     if (state_out) {
         hipLaunchKernelGGL(xrt_export_state_kernel, dim3(1), dim3(64), 0, stream, streams, d_state,

@@ -20,7 +20,7 @@ import ctypes as C
 
 import numpy as np
 
-XRT_ABI_VERSION = 4
+XRT_ABI_VERSION = 5
 XRT_MAX_OPTICS = 16
 XRT_MAX_APERTURES = 8
 XRT_HIST_COMPONENTS = 8
