@@ -146,9 +146,7 @@ def test_library_exports_every_declared_symbol():
 
 
 @pytest.mark.parametrize('name,pattern', [
-    ('W_normal_trace', b'wavelength'), ('S_gaussian_spatial_trace', b'gaussian'),
-    ('G_isotropic_xy_trace', b'isotropic_xy'), ('Q_four_trace', b'more than one Bragg'),
-    ('P_local_trace', b'trace_local')])
+    ('P_local_trace', b'trace_local'), ('D_ToroidalCrystal_trace', b'shape')])
 def test_unsupported_scenes_fail_loudly(name, pattern):
     """No CPU fallback: features outside the device path are refused by xrt_scene_check."""
     cfg, gold = helpers.load_golden(name)
@@ -161,7 +159,8 @@ def test_unsupported_scenes_fail_loudly(name, pattern):
 def test_supported_scenes_validate():
     L = capi.lib()
     for name in ('A_example00_trace', 'B_mirror_trace', 'C_sphere_trace', 'D_CylindricalCrystal_trace',
-                 'P_aperture2_trace', 'W_voigt_trace', 'S_focused_trace', 'G_flat_xy_trace'):
+                 'P_aperture2_trace', 'W_voigt_trace', 'S_focused_trace', 'G_flat_xy_trace',
+                 'W_normal_trace', 'S_gaussian_spatial_trace', 'G_isotropic_xy_trace', 'Q_four_trace'):
         cfg, gold = helpers.load_golden(name)
         config, elements, flat = helpers.build(cfg)
         assert L.xrt_scene_check(flat.byref()) == 0, (name, L.xrt_last_error())

@@ -540,10 +540,12 @@ __device__ __forceinline__ void hist_write(double* hist, uint8_t* hmask, int64_t
 // --------------------------------------------------------------------------
 
 // np.random.seed(int) -> init_genrand, one thread per run (xicsrt_raytrace.py:111)
-__global__ void xrt_seed_kernel(const uint32_t* seeds, KStream* streams, int n_runs)
+__global__ void xrt_seed_kernel(const uint32_t* seeds, KStream* streams, KState* gauss_state, int n_runs)
 {
     int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_runs) return;
+    gauss_state[r].has_gauss = 0;
+    gauss_state[r].gauss = 0.0;
     uint32_t s = seeds[r];
     KStream* st = streams + r;
     for (int i = 0; i < 624; i++) {
@@ -560,10 +562,14 @@ __global__ void xrt_seed_kernel(const uint32_t* seeds, KStream* streams, int n_r
 }
 
 // explicit numpy state -> stream (xrt_trace_history)
-__global__ void xrt_import_state_kernel(const KState* in, KStream* out)
+__global__ void xrt_import_state_kernel(const KState* in, KStream* out, KState* gauss_state)
 {
     for (int i = threadIdx.x; i < 624; i += blockDim.x) out->ring[i] = in->key[i];
-    if (threadIdx.x == 0) { out->gen = 624; out->next = (uint64_t)in->pos; }
+    if (threadIdx.x == 0) {
+        out->gen = 624; out->next = (uint64_t)in->pos;
+        gauss_state[0].has_gauss = in->has_gauss;
+        gauss_state[0].gauss = in->gauss;
+    }
 }
 
 // One wave walks one run's stream forward (no tempering, no workgroup barriers:
@@ -993,6 +999,8 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
     }
 }
 
+#include "xrt_staged.inc"
+
 // ==========================================================================
 // host side of the C ABI
 // ==========================================================================
@@ -1040,22 +1048,18 @@ extern "C" int xrt_scene_check(const xrt_scene_t* sc)
         return fail(-2, "%s", "device path supports at most 8 optics");
     const xrt_source_t& s = sc->source;
     if (s.intensity < 0) return fail(-2, "%s", "negative intensity");
-    if (s.spatial_dist != XRT_SPATIAL_UNIFORM)
-        return fail(-3, "%s", "spatial_dist 'gaussian' is not implemented on the device path");
-    if (s.angular_dist != XRT_ANG_ISOTROPIC && s.angular_dist != XRT_ANG_FLAT && s.angular_dist != XRT_ANG_FLAT_XY)
-        return fail(-3, "%s", "angular_dist 'isotropic_xy' is not implemented on the device path");
-    if (s.wavelength_dist == XRT_WL_NORMAL)
-        return fail(-3, "%s", "gaussian (temperature-only) wavelength sampling is not implemented on the device path");
+    if (s.spatial_dist != XRT_SPATIAL_UNIFORM && s.spatial_dist != XRT_SPATIAL_GAUSSIAN)
+        return fail(-2, "%s", "unknown spatial_dist");
+    if (s.angular_dist < XRT_ANG_ISOTROPIC || s.angular_dist > XRT_ANG_FLAT_XY)
+        return fail(-2, "%s", "unknown angular_dist");
+    if (s.wavelength_dist < XRT_WL_CONST || s.wavelength_dist > XRT_WL_VOIGT)
+        return fail(-2, "%s", "unknown wavelength_dist");
     if (s.wavelength_dist == XRT_WL_VOIGT && (s.voigt_n < 2 || !s.voigt_cdf || !s.voigt_x))
         return fail(-2, "%s", "voigt table missing");
     int n_bragg = 0;
     for (int e = 0; e < sc->n_optics; e++) {
         const xrt_optic_t& o = sc->optics[e];
         if (o.interact == XRT_INTERACT_CRYSTAL && (o.flags & XRT_F_CHECK_BRAGG)) n_bragg++;
-        if (n_bragg > 1)
-            // the reference draws optic k's uniforms for ALL rays before optic k+1's
-            // (array-sequential stream); needs the staged multi-pass path
-            return fail(-3, "%s", "more than one Bragg-checking optic is not implemented on the device path");
         if (o.shape != XRT_SHAPE_PLANE && o.shape != XRT_SHAPE_SPHERE && o.shape != XRT_SHAPE_CYLINDER)
             return fail(-3, "%s", "optic shape is not implemented on the device path");
         if (o.interact < XRT_INTERACT_NONE || o.interact > XRT_INTERACT_CRYSTAL)
@@ -1093,11 +1097,34 @@ static size_t ws_off_polys(const xrt_scene_t* sc, int n_runs)
     return al256(ws_off_heads(sc, n_runs) + sizeof(KStream) * (size_t)n_runs * (size_t)count_heads(sc));
 }
 
+// The staged path (xrt_staged.inc) is needed when the stream is consumed in a data-dependent
+// way before the Bragg uniforms, or by more than one Bragg optic.
+static bool needs_staged(const xrt_scene_t* sc)
+{
+    const xrt_source_t& s = sc->source;
+    if (s.spatial_dist == XRT_SPATIAL_GAUSSIAN || s.angular_dist == XRT_ANG_ISOTROPIC_XY || s.wavelength_dist == XRT_WL_NORMAL)
+        return true;
+    int n_bragg = 0;
+    for (int e = 0; e < sc->n_optics; e++)
+        if (sc->optics[e].interact == XRT_INTERACT_CRYSTAL && (sc->optics[e].flags & XRT_F_CHECK_BRAGG)) n_bragg++;
+    return n_bragg > 1;
+}
+#define XRT_ST_SLOTS 128
+static int staged_slots(int n_runs) { return n_runs < XRT_ST_SLOTS ? (n_runs < 1 ? 1 : n_runs) : XRT_ST_SLOTS; }
+static size_t ws_off_gauss(const xrt_scene_t* sc, int n_runs) { return al256(ws_off_polys(sc, n_runs) + sizeof(uint32_t) * 624 * (XRT_MAX_HEADS + 1)); }
+static size_t ws_off_staged(const xrt_scene_t* sc, int n_runs) { return al256(ws_off_gauss(sc, n_runs) + sizeof(KState) * (size_t)n_runs); }
+static size_t staged_bytes(const xrt_scene_t* sc, int n_runs)
+{
+    if (!needs_staged(sc)) return 0;
+    const size_t n = (size_t)(sc->source.intensity > 0 ? sc->source.intensity : 1);
+    return al256((size_t)staged_slots(n_runs) * n * (XRT_ST_ARRAYS * sizeof(double) + sizeof(uint32_t)) + 256);
+}
+
 extern "C" size_t xrt_workspace_bytes(const xrt_scene_t* sc, int32_t n_runs)
 {
     if (!sc || n_runs < 0) return 0;
     if (n_runs < 1) n_runs = 1;
-    return ws_off_polys(sc, n_runs) + sizeof(uint32_t) * 624 * (XRT_MAX_HEADS + 1) + 256;
+    return ws_off_staged(sc, n_runs) + staged_bytes(sc, n_runs) + 256;
 }
 
 static bool needs_full(const xrt_scene_t* sc)
@@ -1219,6 +1246,34 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
     KStream* streams = reinterpret_cast<KStream*>(ws + ws_off_streams(sc, n_runs));
     KStream* heads = reinterpret_cast<KStream*>(ws + ws_off_heads(sc, n_runs));
     const int64_t N = ks.src.n_rays;
+    if (needs_staged(sc)) {
+        // general path: array-at-a-time passes with one sequential stream head per run
+        KStaged g;
+        memset(&g, 0, sizeof(g));
+        const int slots = staged_slots(n_runs);
+        char* base = ws + ws_off_staged(sc, n_runs);
+        g.arr = reinterpret_cast<double*>(base);
+        g.ids = reinterpret_cast<uint32_t*>(base + (size_t)slots * (size_t)N * XRT_ST_ARRAYS * sizeof(double));
+        g.gauss_state = reinterpret_cast<KState*>(ws + ws_off_gauss(sc, n_runs));
+        for (int i = 0; i < 9; i++) g.spatial_A[i] = sc->source.spatial_A[i];
+        g.spatial_gaussian = sc->source.spatial_dist == XRT_SPATIAL_GAUSSIAN;
+        a.streams = streams; a.heads = heads; a.n_runs = n_runs; a.n_src_heads = nh;
+        a.run_counter = reinterpret_cast<uint32_t*>(ws);
+        HIP_TRY(hipMemsetAsync(ws, 0, 256, stream));
+        const size_t lds = sizeof(double) * XRT_TILE_COMP * XRT_TILE + sizeof(uint32_t) * (XRT_TILE + XRT_RING + 64);
+        int ti = -1;
+        if (timing_on && timing_n < TIMING_MAX) {
+            ti = timing_n++;
+            HIP_TRY(hipEventCreate(&timing_ev[ti][0]));
+            HIP_TRY(hipEventCreate(&timing_ev[ti][1]));
+            HIP_TRY(hipEventRecord(timing_ev[ti][0], stream));
+        }
+        if (hist) hipLaunchKernelGGL(xrt_staged_kernel<true>, dim3(slots), dim3(XRT_TILE), lds, stream, ks, a, g);
+        else      hipLaunchKernelGGL(xrt_staged_kernel<false>, dim3(slots), dim3(XRT_TILE), lds, stream, ks, a, g);
+        HIP_TRY(hipGetLastError());
+        if (ti >= 0) HIP_TRY(hipEventRecord(timing_ev[ti][1], stream));
+        return 0;
+    }
     static const bool no_jump = getenv("XICSRT_NO_JUMP") != nullptr;
     if (canonical && !no_jump && N >= (int64_t)XRT_AHEAD / 2) {
         static thread_local std::vector<uint32_t> hpolys;
@@ -1278,7 +1333,8 @@ extern "C" int xrt_trace(const xrt_scene_t* sc, const uint32_t* seeds, int32_t n
     uint32_t* d_seeds = reinterpret_cast<uint32_t*>(ws + ws_off_seeds(sc));
     KStream* streams = reinterpret_cast<KStream*>(ws + ws_off_streams(sc, n_runs));
     HIP_TRY(hipMemcpyAsync(d_seeds, seeds, sizeof(uint32_t) * (size_t)n_runs, hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(xrt_seed_kernel, dim3((n_runs + 63) / 64), dim3(64), 0, stream, d_seeds, streams, n_runs);
+    hipLaunchKernelGGL(xrt_seed_kernel, dim3((n_runs + 63) / 64), dim3(64), 0, stream, d_seeds, streams,
+                       reinterpret_cast<KState*>(ws + ws_off_gauss(sc, n_runs)), n_runs);
     HIP_TRY(hipGetLastError());
     st = upload_tables(sc, ws, stream);
     if (st) return st;
@@ -1312,7 +1368,8 @@ extern "C" int xrt_trace_history(const xrt_scene_t* sc, const xrt_rng_state_t* s
     KState* d_state = reinterpret_cast<KState*>(ws + ws_off_state(sc));
     KStream* streams = reinterpret_cast<KStream*>(ws + ws_off_streams(sc, 1));
     HIP_TRY(hipMemcpyAsync(d_state, state_in, sizeof(KState), hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(xrt_import_state_kernel, dim3(1), dim3(64), 0, stream, d_state, streams);
+    hipLaunchKernelGGL(xrt_import_state_kernel, dim3(1), dim3(64), 0, stream, d_state, streams,
+                       reinterpret_cast<KState*>(ws + ws_off_gauss(sc, 1)));
     HIP_TRY(hipGetLastError());
     st = upload_tables(sc, ws, stream);
     if (st) return st;
@@ -1326,7 +1383,8 @@ extern "C" int xrt_trace_history(const xrt_scene_t* sc, const xrt_rng_state_t* s
     st = run_iteration(sc, ks, ws, a, 1, true, false, stream);
     if (st) return st;
     if (state_out) {
-        hipLaunchKernelGGL(xrt_export_state_kernel, dim3(1), dim3(64), 0, stream, streams, d_state,
+        hipLaunchKernelGGL(xrt_export_state_kernel, dim3(1), dim3(64), 0, stream, streams,
+                           reinterpret_cast<const KState*>(ws + ws_off_gauss(sc, 1)),
                            reinterpret_cast<KState*>(state_out));
         HIP_TRY(hipGetLastError());
     }
