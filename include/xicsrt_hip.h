@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define XRT_ABI_VERSION 5
+#define XRT_ABI_VERSION 6
 
 #define XRT_MAX_OPTICS     16
 #define XRT_MAX_APERTURES  8
@@ -139,7 +139,9 @@ typedef struct xrt_optic {
     double  center[3];        /* sphere / cylinder / torus centre (_ShapeSphere.py:43)     */
     double  torus_major;      /* torus frame major radius (_ShapeTorus.py:72-91)           */
     double  torus_minor;
-    int32_t torus_root;       /* quartic root column                                       */
+    double  torus_k[5];       /* host constants of the quartic (_ShapeTorus.py:139-159):
+                               * r_sq = R^2+r^2, 2*r_sq, 4*R^2, 8*R^2, (R^2-r^2)^2         */
+    int32_t torus_root;       /* quartic root column (_ShapeTorus.py:72-89)                */
     int32_t n_apertures;
     double  two_d;            /* 2*crystal_spacing            (_InteractCrystal.py:110)    */
     double  reflectivity;

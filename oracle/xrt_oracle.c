@@ -474,6 +474,113 @@ static void intersect_cylinder(const xrt_optic_t* op, rays_t* r)
     }
 }
 
+/* tools/xicsrt_quartic.py:54-160 multi_cubic(1, b0, c0, d0, all_roots=False): one real root */
+static double cubic_one_root(double a, double b, double c)
+{
+    const double third = 1. / 3.;
+    double a13 = a * third;
+    double a2 = a13 * a13;
+    double f = third * b - a2;
+    double g = a13 * (2 * a2 - b) + c;
+    double h = 0.25 * g * g + f * f * f;
+    if (f == 0 && g == 0 && h == 0) {                 /* m1: all roots real and equal */
+        double cr = (c >= 0) ? pow(c, third) : -pow(-c, third);
+        return -cr;
+    }
+    if (h <= 0) {                                     /* m2: real and distinct */
+        double j = sqrt(-f);
+        double k = acos(-0.5 * g / (j * j * j));
+        double m = cos(third * k);
+        return 2 * j * m - a13;
+    }
+    {                                                 /* m3: one real root */
+        double sqrt_h = sqrt(h);
+        double x1 = -0.5 * g + sqrt_h, x2 = -0.5 * g - sqrt_h;
+        double S = (x1 >= 0) ? pow(x1, third) : -pow(-x1, third);
+        double U = (x2 >= 0) ? pow(x2, third) : -pow(-x2, third);
+        return (S + U) - a13;
+    }
+}
+
+/* tools/xicsrt_quartic.py:162-207 multi_quartic with a0 = 1, restated in real arithmetic:
+ * the reference works in complex128 and then discards every root whose imaginary part is
+ * not exactly zero (_ShapeTorus.py:164-167).  The imaginary parts are exactly zero iff
+ * s = sqrt(2p + 2 z0) is real and the quadratic's discriminant is >= 0; complex division
+ * by a real s is numpy's Smith form x * (1.0 / s). */
+static void quartic_roots(double b0, double c0, double d0, double e0, double roots[4])
+{
+    double a = b0, b = c0, c = d0, d = e0;            /* division by a0 = 1 is exact */
+    double a0 = 0.25 * a;
+    double a02 = a0 * a0;
+    double p = 3 * a02 - 0.5 * b;
+    double q = a * a02 - b * a0 + 0.5 * c;
+    double r = 3 * a02 * a02 - b * a02 + c * a0 - d;
+    double z0 = cubic_one_root(p, r, p * r - 0.5 * q * q);
+    double sarg = 2 * p + 2 * z0;
+    roots[0] = roots[1] = roots[2] = roots[3] = NAN;
+    if (!(sarg >= 0.0)) return;                       /* s imaginary (or NaN): every root complex */
+    double s = sqrt(sarg);
+    double t = (s == 0.0) ? (z0 * z0 + r) : (-q) * (1.0 / s);
+    {   /* multi_quadratic(1, s, z0 + t) - a0 */
+        double h0 = -0.5 * s;
+        double delta = h0 * h0 - (z0 + t);
+        if (delta >= 0.0) {
+            double sd = sqrt(delta);
+            roots[0] = (h0 - sd) - a0;
+            roots[1] = (h0 + sd) - a0;
+        }
+    }
+    {   /* multi_quadratic(1, -s, z0 - t) - a0 */
+        double h0 = -0.5 * (-s);
+        double delta = h0 * h0 - (z0 - t);
+        if (delta >= 0.0) {
+            double sd = sqrt(delta);
+            roots[2] = (h0 - sd) - a0;
+            roots[3] = (h0 + sd) - a0;
+        }
+    }
+}
+
+/* optics/_ShapeTorus.py:110-216 */
+static void intersect_torus(const xrt_optic_t* op, rays_t* r)
+{
+    const double* R = op->orientation;
+    const double* ya = &R[3];
+    const double Rt = op->torus_major;
+    for (int64_t i = 0; i < r->n; i++) {
+        if (!r->mask[i]) continue;
+        const double* o = &r->o[3 * i];
+        const double* d = &r->d[3 * i];
+        double v[3] = {o[0] - op->center[0], o[1] - op->center[1], o[2] - op->center[2]};
+        double O[3], D[3];
+        to_local(R, v, O);
+        to_local(R, d, D);
+        double O_mag_sq = dot_e(O, O), dot_OD = dot_e(O, D);
+        const double r_sq = op->torus_k[0], two_r_sq = op->torus_k[1], four_R2 = op->torus_k[2],
+                     eight_R2 = op->torus_k[3], K = op->torus_k[4];
+        double c1 = 4.0 * dot_OD;
+        double c2 = ((4.0 * (dot_OD * dot_OD) + 2.0 * O_mag_sq) - two_r_sq) + four_R2 * (D[1] * D[1]);
+        double c3 = (4.0 * dot_OD) * (O_mag_sq - r_sq) + (eight_R2 * D[1]) * O[1];
+        double c4 = ((O_mag_sq * O_mag_sq - two_r_sq * O_mag_sq) + four_R2 * (O[1] * O[1])) + K;
+        double roots[4];
+        quartic_roots(c1, c2, c3, c4, roots);
+        double t = roots[op->torus_root];
+        if (!(isfinite(t) && t > 0.0)) { r->mask[i] = 0; continue; }
+        double* x = &r->x[3 * i];
+        location_from_distance(o, d, t, x);
+        /* intersect_normal (:186-216) */
+        double pt[3] = {x[0] - op->center[0], x[1] - op->center[1], x[2] - op->center[2]};
+        double dy = dot_e(pt, ya);
+        for (int k = 0; k < 3; k++) pt[k] = pt[k] - dy * ya[k];
+        double m = norm3(pt);
+        double Q[3];
+        for (int k = 0; k < 3; k++) Q[k] = op->center[k] + Rt * (pt[k] / m);
+        double xn[3] = {x[0] - Q[0], x[1] - Q[1], x[2] - Q[2]};
+        double m2 = norm3(xn);
+        for (int k = 0; k < 3; k++) r->nrm[3 * i + k] = xn[k] / m2;
+    }
+}
+
 /* tools/xicsrt_aperture.py:108-204: single shape test on local coordinates */
 static int aperture_shape(const xrt_aperture_t* a, const double* X)
 {
@@ -586,6 +693,7 @@ static void trace_optic(const xrt_optic_t* op, rays_t* r, mt_t* mt)
     case XRT_SHAPE_PLANE:    intersect_plane(op, r); break;
     case XRT_SHAPE_SPHERE:   intersect_sphere(op, r); break;
     case XRT_SHAPE_CYLINDER: intersect_cylinder(op, r); break;
+    case XRT_SHAPE_TORUS:    intersect_torus(op, r); break;
     }
     memcpy(r->hit, r->mask, (size_t)r->n);
     check_bounds(op, r);

@@ -146,7 +146,7 @@ def test_library_exports_every_declared_symbol():
 
 
 @pytest.mark.parametrize('name,pattern', [
-    ('P_local_trace', b'trace_local'), ('D_ToroidalCrystal_trace', b'shape')])
+    ('P_local_trace', b'trace_local')])
 def test_unsupported_scenes_fail_loudly(name, pattern):
     """No CPU fallback: features outside the device path are refused by xrt_scene_check."""
     cfg, gold = helpers.load_golden(name)

@@ -9,7 +9,7 @@ import pytest
 import helpers
 
 # golden cases whose features the oracle / device path implement so far
-SKIP_PREFIX = ('D_ToroidalCrystal', 'E_mesh', 'F_plasma', 'P_local')
+SKIP_PREFIX = ('E_mesh', 'F_plasma', 'P_local')
 
 
 def _cases(kind):

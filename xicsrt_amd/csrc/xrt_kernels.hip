@@ -76,6 +76,9 @@ struct KOptic {
     double  half_size[3];
     double  radius, radius2;
     double  center[3];
+    double  torus_major;
+    double  torus_k[5];
+    int32_t torus_root, pad0;
     double  two_d, reflectivity, half_fwhm, two_sigma2, half_pi;
     double  pixel_size, pixel_xoff, pixel_yoff;
     int32_t pixel_nx, pixel_ny;
@@ -342,6 +345,58 @@ __device__ __forceinline__ void source_ray(const KSource& s, const double* u, Ra
 // optics
 // --------------------------------------------------------------------------
 
+// tools/xicsrt_quartic.py:54-160 multi_cubic(1, b0, c0, d0, all_roots=False): one real root
+__device__ double cubic_one_root(double a, double b, double c)
+{
+    const double third = 1. / 3.;
+    double a13 = a * third;
+    double a2 = a13 * a13;
+    double f = third * b - a2;
+    double g = a13 * (2 * a2 - b) + c;
+    double h = 0.25 * g * g + f * f * f;
+    if (f == 0 && g == 0 && h == 0) {
+        double cr = (c >= 0) ? pow(c, third) : -pow(-c, third);
+        return -cr;
+    }
+    if (h <= 0) {
+        double j = sqrt(-f);
+        double k = acos(-0.5 * g / (j * j * j));
+        double m = cos(third * k);
+        return 2 * j * m - a13;
+    }
+    double sqrt_h = sqrt(h);
+    double x1 = -0.5 * g + sqrt_h, x2 = -0.5 * g - sqrt_h;
+    double S = (x1 >= 0) ? pow(x1, third) : -pow(-x1, third);
+    double U = (x2 >= 0) ? pow(x2, third) : -pow(-x2, third);
+    return (S + U) - a13;
+}
+
+// tools/xicsrt_quartic.py:162-207 multi_quartic (a0 = 1) in real arithmetic; the reference's
+// complex128 roots are kept only when their imaginary part is exactly zero
+// (optics/_ShapeTorus.py:164-167), i.e. when s = sqrt(2p + 2 z0) is real and the
+// quadratic's discriminant is >= 0.  Division of a real by the real s is numpy's
+// Smith-form complex division: x * (1.0 / s).  Returns root number `which`.
+__device__ double quartic_root(double b0, double c0, double d0, double e0, int which)
+{
+    double a = b0, b = c0, c = d0, d = e0;
+    double a0 = 0.25 * a;
+    double a02 = a0 * a0;
+    double p = 3 * a02 - 0.5 * b;
+    double q = a * a02 - b * a0 + 0.5 * c;
+    double r = 3 * a02 * a02 - b * a02 + c * a0 - d;
+    double z0 = cubic_one_root(p, r, p * r - 0.5 * q * q);
+    double sarg = 2 * p + 2 * z0;
+    if (!(sarg >= 0.0)) return __builtin_nan("");
+    double s = sqrt(sarg);
+    double t = (s == 0.0) ? (z0 * z0 + r) : (-q) * (1.0 / s);
+    double h0, delta;
+    if (which < 2) { h0 = -0.5 * s;    delta = h0 * h0 - (z0 + t); }
+    else           { h0 = -0.5 * (-s); delta = h0 * h0 - (z0 - t); }
+    if (!(delta >= 0.0)) return __builtin_nan("");
+    double sd = sqrt(delta);
+    return ((which & 1) ? (h0 + sd) : (h0 - sd)) - a0;
+}
+
 // Shape*.intersect_distance + location_from_distance: the intersection point.
 // Returns false when the ray has no intersection (mask &= ... in the reference).
 template <bool FULL>
@@ -364,6 +419,19 @@ __device__ __forceinline__ bool intersect_point(const KOptic& op, const Ray& ray
         double t0 = t_ca - t_hc, t1 = t_ca + t_hc;
         if (op.flags & XRT_F_CONVEX) t = (t0 < t1) ? t0 : t1;
         else                         t = (t0 > t1) ? t0 : t1;
+    } else if (op.shape == XRT_SHAPE_TORUS) {
+        // optics/_ShapeTorus.py:110-183: quartic in the torus frame (axis = local y)
+        V3 O = to_local(op.R, sub3(ray.o, ld3(op.center)));
+        V3 D = to_local(op.R, ray.d);
+        double O_mag_sq = dot_e(O, O), dot_OD = dot_e(O, D);
+        const double r_sq = op.torus_k[0], two_r_sq = op.torus_k[1], four_R2 = op.torus_k[2],
+                     eight_R2 = op.torus_k[3], K = op.torus_k[4];
+        double c1 = 4.0 * dot_OD;
+        double c2 = ((4.0 * (dot_OD * dot_OD) + 2.0 * O_mag_sq) - two_r_sq) + four_R2 * (D.y * D.y);
+        double c3 = (4.0 * dot_OD) * (O_mag_sq - r_sq) + (eight_R2 * D.y) * O.y;
+        double c4 = ((O_mag_sq * O_mag_sq - two_r_sq * O_mag_sq) + four_R2 * (O.y * O.y)) + K;
+        t = quartic_root(c1, c2, c3, c4, op.torus_root);
+        if (!(isfinite(t) && t > 0.0)) return false;
     } else {
         // optics/_ShapeCylinder.py:52-110
         V3 pa = ld3(op.center), va = ld3(op.R + 0);
@@ -399,6 +467,18 @@ __device__ __forceinline__ V3 surface_normal(const KOptic& op, const V3& X)
         V3 q = sub3(ld3(op.center), X);             // optics/_ShapeSphere.py:102-106
         double m = norm3(q);
         nrm.x = q.x / m; nrm.y = q.y / m; nrm.z = q.z / m;
+    } else if (op.shape == XRT_SHAPE_TORUS) {
+        // optics/_ShapeTorus.py:186-216: away from the nearest point of the major circle
+        V3 C = ld3(op.center), ya = ld3(op.R + 3);
+        V3 pt = sub3(X, C);
+        double dy = dot_e(pt, ya);
+        pt.x = pt.x - dy * ya.x; pt.y = pt.y - dy * ya.y; pt.z = pt.z - dy * ya.z;
+        double m = norm3(pt);
+        V3 Q;
+        Q.x = C.x + op.torus_major * (pt.x / m); Q.y = C.y + op.torus_major * (pt.y / m); Q.z = C.z + op.torus_major * (pt.z / m);
+        V3 xn = sub3(X, Q);
+        double m2 = norm3(xn);
+        nrm.x = xn.x / m2; nrm.y = xn.y / m2; nrm.z = xn.z / m2;
     } else {
         V3 pa = ld3(op.center), va = ld3(op.R + 0); // optics/_ShapeCylinder.py:112-133
         V3 q = sub3(pa, X);
@@ -1056,12 +1136,12 @@ extern "C" int xrt_scene_check(const xrt_scene_t* sc)
         return fail(-2, "%s", "unknown wavelength_dist");
     if (s.wavelength_dist == XRT_WL_VOIGT && (s.voigt_n < 2 || !s.voigt_cdf || !s.voigt_x))
         return fail(-2, "%s", "voigt table missing");
-    int n_bragg = 0;
     for (int e = 0; e < sc->n_optics; e++) {
         const xrt_optic_t& o = sc->optics[e];
-        if (o.interact == XRT_INTERACT_CRYSTAL && (o.flags & XRT_F_CHECK_BRAGG)) n_bragg++;
-        if (o.shape != XRT_SHAPE_PLANE && o.shape != XRT_SHAPE_SPHERE && o.shape != XRT_SHAPE_CYLINDER)
+        if (o.shape < XRT_SHAPE_PLANE || o.shape > XRT_SHAPE_TORUS)
             return fail(-3, "%s", "optic shape is not implemented on the device path");
+        if (o.shape == XRT_SHAPE_TORUS && (o.torus_root < 0 || o.torus_root > 3))
+            return fail(-2, "%s", "torus root index out of range");
         if (o.interact < XRT_INTERACT_NONE || o.interact > XRT_INTERACT_CRYSTAL)
             return fail(-3, "%s", "optic interaction is not implemented on the device path");
         if (o.flags & XRT_F_TRACE_LOCAL)
@@ -1133,7 +1213,7 @@ static bool needs_full(const xrt_scene_t* sc)
     if (s.kind == XRT_SRC_FOCUSED || s.angular_dist != XRT_ANG_ISOTROPIC || s.wavelength_dist == XRT_WL_VOIGT) return true;
     for (int e = 0; e < sc->n_optics; e++) {
         const xrt_optic_t& o = sc->optics[e];
-        if (o.shape == XRT_SHAPE_CYLINDER) return true;
+        if (o.shape == XRT_SHAPE_CYLINDER || o.shape == XRT_SHAPE_TORUS) return true;
         if ((o.flags & XRT_F_CHECK_APERTURE) && o.n_apertures > 0) return true;
     }
     return false;
@@ -1177,6 +1257,8 @@ static void build_kscene(const xrt_scene_t* sc, char* ws, KScene* k)
         for (int i = 0; i < 3; i++) { q.origin[i] = o.origin[i]; q.half_size[i] = o.half_size[i]; q.center[i] = o.center[i]; }
         for (int i = 0; i < 9; i++) q.R[i] = o.orientation[i];
         q.radius = o.radius; q.radius2 = o.radius2;
+        q.torus_major = o.torus_major; q.torus_root = o.torus_root;
+        for (int i = 0; i < 5; i++) q.torus_k[i] = o.torus_k[i];
         q.two_d = o.two_d; q.reflectivity = o.reflectivity; q.half_fwhm = o.rocking_half_fwhm;
         q.two_sigma2 = o.rocking_2sigma2; q.half_pi = o.half_pi;
         q.pixel_size = o.pixel_size; q.pixel_xoff = o.pixel_xoff; q.pixel_yoff = o.pixel_yoff;

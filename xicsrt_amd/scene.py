@@ -20,7 +20,7 @@ import ctypes as C
 
 import numpy as np
 
-XRT_ABI_VERSION = 5
+XRT_ABI_VERSION = 6
 XRT_MAX_OPTICS = 16
 XRT_MAX_APERTURES = 8
 XRT_HIST_COMPONENTS = 8
@@ -66,7 +66,7 @@ class Optic(C.Structure):
                 ('origin', C.c_double * 3), ('orientation', C.c_double * 9),
                 ('half_size', C.c_double * 3),
                 ('radius', C.c_double), ('radius2', C.c_double), ('center', C.c_double * 3),
-                ('torus_major', C.c_double), ('torus_minor', C.c_double),
+                ('torus_major', C.c_double), ('torus_minor', C.c_double), ('torus_k', C.c_double * 5),
                 ('torus_root', C.c_int32), ('n_apertures', C.c_int32),
                 ('two_d', C.c_double), ('reflectivity', C.c_double),
                 ('rocking_half_fwhm', C.c_double), ('rocking_2sigma2', C.c_double),
@@ -294,6 +294,7 @@ def flatten_optic(obj, out, image_offset):
     _vec(out.center, np.zeros(3))
     out.torus_major = out.torus_minor = 0.0
     out.torus_root = 0
+    _vec(out.torus_k, np.zeros(5))
     if obj.shape_kind in ('sphere', 'cylinder'):
         out.radius = float(p['radius'])
         out.radius2 = float(p['radius'] ** 2)
@@ -305,6 +306,10 @@ def flatten_optic(obj, out, image_offset):
         out.torus_minor = float(p['torus_minor'])
         out.torus_root = int(p['root_idx'])
         _vec(out.center, p['center'])
+        r_major, r_minor = p['torus_major'], p['torus_minor']
+        r_sq = r_major ** 2 + r_minor ** 2
+        _vec(out.torus_k, [r_sq, 2 * r_sq, 4 * r_major ** 2, 8 * r_major ** 2,
+                           (r_major ** 2 - r_minor ** 2) ** 2])
 
     out.rocking_type = ROCKING_GAUSS
     out.two_d = out.rocking_half_fwhm = out.rocking_2sigma2 = 0.0
