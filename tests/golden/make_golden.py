@@ -270,6 +270,13 @@ def build_cases():
     cfg2['sources']['source']['intensity'] = 50000
     add('Q_four_counts', 'counts', cfg2)
 
+    # --- full results dictionary with histories (found / shuffled lost sample) ---
+    cfg = cfg_three(3000, dict(sph, rocking_fwhm=2e-3), seed=81, runs=2, iters=2, history=True)
+    cfg['general']['history_max_lost'] = 200
+    add('H_history_runs_iters', 'history', cfg)
+    cfg = cfg_three(2000, mir, seed=82, history=True)
+    add('H_history_mirror', 'history', cfg)
+
     # --- plasma cube (BASELINE cfg4 shape, small) ---------------------------
     p = {'class_name': 'XicsrtPlasmaCubic', 'origin': [0.0, 0.0, 0.0],
          'xsize': 0.1, 'ysize': 0.1, 'zsize': 0.1,
@@ -377,6 +384,26 @@ def dump_class_defaults():
     print('class_defaults.json:', {k: len(v) for k, v in out.items()})
 
 
+def run_history(cfg):
+    """xicsrt.raytrace with keep_history=True: totals + found / lost ray histories."""
+    cfg = copy.deepcopy(cfg)
+    res = xicsrt.raytrace(cfg)
+    out = {}
+    names = list(res['total']['meta'].keys())
+    out['names'] = np.array(names)
+    for k in names:
+        out['num_out/' + k] = np.int64(res['total']['meta'][k]['num_out'])
+        img = res['total']['image'].get(k)
+        if img is not None:
+            out['image/' + k] = img.astype(np.int64)
+        for group in ('found', 'lost'):
+            h = res[group]['history'][k]
+            assert sorted(h.keys()) == ['direction', 'mask', 'origin', 'wavelength']
+            for key in ('origin', 'direction', 'wavelength', 'mask'):
+                out['%s/%s/%s' % (group, key, k)] = np.asarray(h[key])
+    return out
+
+
 def main(argv):
     if argv[1:] == ['class_defaults']:
         dump_class_defaults()
@@ -390,7 +417,7 @@ def main(argv):
     for name in want:
         kind, cfg = cases[name]
         try:
-            out = run_trace(cfg) if kind == 'trace' else run_counts(cfg)
+            out = {'trace': run_trace, 'counts': run_counts, 'history': run_history}[kind](cfg)
         except Exception as e:  # reference raised: record that, it is part of the contract
             print('%-32s REFERENCE RAISED %s: %s' % (name, type(e).__name__, e))
             continue

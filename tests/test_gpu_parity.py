@@ -123,3 +123,50 @@ def test_run_partition_invariance(devlib):
             total = (acc_n, acc_i)
         assert np.array_equal(total[0], acc_n) and np.array_equal(total[1], acc_i)
     assert int(total[0][2]) == int(gold['num_out/detector'])
+
+
+@pytest.mark.parametrize('name', ['H_history_runs_iters', 'H_history_mirror'])
+def test_raytrace_with_history_matches_reference(name, devlib):
+    """
+    keep_history=True through xicsrt.raytrace: found rays in full, lost rays as the reference's
+    shuffled truncation (np.random.shuffle on the run's own stream between iterations,
+    xicsrt_raytrace.py:253-274), concatenated over iterations and runs (:359-390).
+    """
+    import xicsrt_amd as xicsrt
+    cfg, gold = helpers.load_golden(name)
+    res = xicsrt.raytrace(cfg)
+    names = [str(n) for n in gold['names']]
+    assert list(res['total']['meta'].keys()) == names
+    for nm in names:
+        assert int(res['total']['meta'][nm]['num_out']) == int(gold['num_out/' + nm]), nm
+        if 'image/' + nm in gold:
+            assert np.array_equal(res['total']['image'][nm].astype(np.int64), gold['image/' + nm])
+        for group in ('found', 'lost'):
+            h = res[group]['history'][nm]
+            assert sorted(h.keys()) == ['direction', 'mask', 'origin', 'wavelength']
+            assert np.array_equal(h['mask'], gold['%s/mask/%s' % (group, nm)]), (group, nm)
+            for key in ('origin', 'direction', 'wavelength'):
+                g = gold['%s/%s/%s' % (group, key, nm)]
+                assert np.array_equal(np.isnan(h[key]), np.isnan(g)), (group, key, nm)
+                ok = ~np.isnan(g)
+                if ok.any():
+                    assert np.max(np.abs(h[key][ok] - g[ok])) <= FLOAT_RTOL * max(1.0, np.max(np.abs(g[ok]))), (group, key, nm)
+
+
+def test_source_object_generate_rays_uses_global_numpy_state(devlib):
+    """XicsrtSource*.generate_rays(): np.random global state in -> rays -> advanced state out."""
+    import xicsrt_amd as xicsrt
+    cfg, gold = helpers.load_golden('S_extended_trace')
+    src = xicsrt.get_element(cfg, 'source')
+    np.random.seed(cfg['general']['random_seed'])
+    rays = src.generate_rays()
+    assert set(rays.keys()) == {'origin', 'direction', 'wavelength', 'weight', 'mask'}
+    assert np.all(rays['mask']) and np.all(rays['weight'] == 1.0)
+    for key in ('origin', 'direction', 'wavelength'):
+        g = gold[key + '/source']
+        assert np.max(np.abs(rays[key] - g)) <= FLOAT_RTOL * np.max(np.abs(g))
+    # the stream advanced by exactly the source's 5 arrays of N doubles
+    after = np.random.random_sample()
+    ref = np.random.RandomState(cfg['general']['random_seed'])
+    ref.random_sample(5 * 500)
+    assert after == ref.random_sample()

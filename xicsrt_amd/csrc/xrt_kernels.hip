@@ -798,7 +798,11 @@ void xrt_jump_kernel(KStream* streams, KStream* heads, const uint32_t* polys, in
     }
 }
 
-// stream -> numpy state: key = the 624-word block that contains `next`
+// stream -> numpy state.  numpy keeps key = the 624-word block that contains the
+// next word and pos = the offset in it; when that block is still inside the ring it is
+// reproduced exactly.  Otherwise (the head ran more than 400 words ahead) an
+// equivalent state is written: key = the last 624 words generated, pos = 624 - words
+// ahead; the recurrence is translation invariant, so both continue the same stream.
 __global__ __launch_bounds__(64)
 void xrt_export_state_kernel(const KStream* in, const KState* orig, KState* out)
 {
@@ -808,8 +812,12 @@ void xrt_export_state_kernel(const KStream* in, const KState* orig, KState* out)
     uint64_t gen = uni64(in->gen);
     const uint64_t next = uni64(in->next);
     wave_fence();
-    const uint64_t block = (next == 0) ? 0 : ((next - 1) / 624ull) * 624ull;
-    wave_walk(ring, gen, block + 624ull, lane);
+    uint64_t block = (next == 0) ? 0 : ((next - 1) / 624ull) * 624ull;
+    if (gen > block + 1024ull) {
+        block = gen - 624ull;
+    } else {
+        wave_walk(ring, gen, block + 624ull, lane);
+    }
     for (int i = lane; i < 624; i += 64) out->key[i] = ring[((uint32_t)block + (uint32_t)i) & XRT_RMASK];
     if (lane == 0) {
         out->pos = (int32_t)(next - block);
@@ -1068,7 +1076,7 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
         // ---- run done: counters out, stream head back to memory ---------------
         // canonical form: exactly 512 words generated ahead (what xrt_jump_kernel expects)
         __syncthreads();
-        while ((sgen - spos) < XRT_AHEAD) { mt_step(); __syncthreads(); }
+        if (!HIST) while ((sgen - spos) < XRT_AHEAD) { mt_step(); __syncthreads(); }
         if (tid <= sc.n_optics && cnt[tid] != 0ULL) atomicAdd(&args.num_out[tid], cnt[tid]);
         for (int i = tid; i < (int)XRT_RING; i += XRT_TILE) st->ring[i] = stream[i];
         if (tid == 0) {
