@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define XRT_ABI_VERSION 6
+#define XRT_ABI_VERSION 7
 
 #define XRT_MAX_OPTICS     16
 #define XRT_MAX_APERTURES  8
@@ -50,7 +50,8 @@ extern "C" {
 
 /* cone-axis rule of the source (sources/_XicsrtSourceGeneric.py:262,
  * _XicsrtSourceDirected.py:46, _XicsrtSourceFocused.py:40) */
-enum { XRT_SRC_GENERIC = 0, XRT_SRC_DIRECTED = 1, XRT_SRC_FOCUSED = 2 };
+enum { XRT_SRC_GENERIC = 0, XRT_SRC_DIRECTED = 1, XRT_SRC_FOCUSED = 2,
+       XRT_SRC_PLASMA = 3   /* XicsrtPlasma*: bundles of focused sources (sources/_XicsrtPlasmaGeneric.py:252-382) */ };
 /* spatial_dist (_XicsrtSourceGeneric.py:231,237) */
 enum { XRT_SPATIAL_UNIFORM = 0, XRT_SPATIAL_GAUSSIAN = 1 };
 /* angular_dist (tools/xicsrt_spread.py:21) */
@@ -124,6 +125,15 @@ typedef struct xrt_source {
     double  light_speed;      /* scipy.constants c                                         */
     const double* voigt_cdf;  /* HOST pointers, voigt_n doubles each; copied per call      */
     const double* voigt_x;
+    /* XRT_SRC_PLASMA only.  `intensity` is then the ray CAPACITY per iteration (the
+     * actual count is Poisson distributed and reported in num_out[0]); `size` is the
+     * bundle voxel edge (x3), `axis` the target, the cone/wavelength fields describe
+     * every bundle (XicsrtPlasmaCubic: constant temperature, emissivity, spread). */
+    int64_t bundle_count;     /* param['bundle_count']       (_XicsrtPlasmaGeneric.py:166-168) */
+    double  plasma_size[3];   /* xsize, ysize, zsize of the plasma box (bundle centres, :195-197) */
+    double  bundle_intensity; /* expected rays per bundle     (:301-319)                    */
+    int32_t use_poisson;      /* np.random.poisson(intensity) per bundle, else int(intensity) */
+    int32_t pad_plasma;
 } xrt_source_t;
 
 typedef struct xrt_optic {
@@ -233,6 +243,10 @@ int xrt_trace_history(const xrt_scene_t* scene, const xrt_rng_state_t* state_in,
                       double* rays, uint8_t* mask, void* state_out,
                       void* workspace, size_t workspace_bytes,
                       void* stream);
+
+/* Synchronises `stream` and reports conditions the asynchronous calls could only flag on the
+ * device (a plasma source that produced more rays than the declared capacity): 0 = clean. */
+int xrt_check(void* workspace, void* stream);
 
 /* Diagnostic, host only: the MT19937 jump-ahead polynomial g(t) = t^J mod phi(t)
  * (phi = characteristic polynomial of the generator, degree 19937) that positions

@@ -115,6 +115,59 @@ static double mt_gauss(mt_t* s)
     return f * x2;
 }
 
+/* numpy legacy random_poisson (numpy/random/src/distributions/distributions.c):
+ * PTRS transformed rejection for lam >= 10, multiplication method below */
+static double random_loggam(double x)
+{
+    static const double a[10] = {8.333333333333333e-02, -2.777777777777778e-03, 7.936507936507937e-04,
+                                 -5.952380952380952e-04, 8.417508417508418e-04, -1.917526917526918e-03,
+                                 6.410256410256410e-03, -2.955065359477124e-02, 1.796443723688307e-01,
+                                 -1.39243221690590e+00};
+    double x0, x2, lg2pi, gl, gl0;
+    long k, n;
+    if ((x == 1.0) || (x == 2.0)) return 0.0;
+    else if (x < 7.0) n = (long)(7 - x);
+    else n = 0;
+    x0 = x + n;
+    x2 = (1.0 / x0) * (1.0 / x0);
+    lg2pi = 1.8378770664093453e+00;
+    gl0 = a[9];
+    for (k = 8; k >= 0; k--) { gl0 *= x2; gl0 += a[k]; }
+    gl = gl0 / x0 + 0.5 * lg2pi + (x0 - 0.5) * log(x0) - x0;
+    if (x < 7.0) for (k = 1; k <= n; k++) { gl -= log(x0 - 1.0); x0 -= 1.0; }
+    return gl;
+}
+
+static int64_t mt_poisson(mt_t* s, double lam)
+{
+    if (lam >= 10) {
+        double slam = sqrt(lam), loglam = log(lam);
+        double b = 0.931 + 2.53 * slam;
+        double a = -0.059 + 0.02483 * b;
+        double invalpha = 1.1239 + 1.1328 / (b - 3.4);
+        double vr = 0.9277 - 3.6224 / (b - 2);
+        for (;;) {
+            double U = mt_double(s) - 0.5;
+            double V = mt_double(s);
+            double us = 0.5 - fabs(U);
+            int64_t k = (int64_t)floor((2 * a / us + b) * U + lam + 0.43);
+            if ((us >= 0.07) && (V <= vr)) return k;
+            if ((k < 0) || ((us < 0.013) && (V > us))) continue;
+            if ((log(V) + log(invalpha) - log(a / (us * us) + b)) <= (-lam + k * loglam - random_loggam(k + 1))) return k;
+        }
+    } else if (lam == 0) {
+        return 0;
+    } else {
+        double enlam = exp(-lam), prod = 1.0;
+        int64_t X = 0;
+        for (;;) {
+            double U = mt_double(s);
+            prod *= U;
+            if (prod > enlam) X += 1; else return X;
+        }
+    }
+}
+
 /* ------------------------------------------------------------------------ */
 /* small numeric helpers with numpy's evaluation order                        */
 /* ------------------------------------------------------------------------ */
@@ -296,10 +349,15 @@ static void vector_distribution(const xrt_source_t* s, mt_t* mt, double* lv /*[n
     }
 }
 
-/* sources/_XicsrtSourceGeneric.py:198-227 */
-static void generate_rays(const xrt_source_t* s, mt_t* mt, rays_t* r)
+/* sources/_XicsrtSourceGeneric.py:198-227: n rays of one source object written at ray index
+ * `base` (a plasma bundle is a focused source whose origin is the bundle centre) */
+static void generate_block(const xrt_source_t* s, const double* origin3, mt_t* mt, rays_t* rr, int64_t base, int64_t n)
 {
-    const int64_t n = r->n;
+    rays_t view = *rr;
+    view.n = n;
+    view.o = rr->o + 3 * base; view.d = rr->d + 3 * base; view.wl = rr->wl + base; view.wt = rr->wt + base;
+    view.mask = rr->mask + base; view.nrm = rr->nrm + 3 * base; view.loc = rr->loc + 3 * base;
+    rays_t* r = &view;
     const double* R = s->orientation;
     const double* xa = &R[0];
     const double* ya = &R[3];
@@ -327,13 +385,13 @@ static void generate_rays(const xrt_source_t* s, mt_t* mt, rays_t* r)
     }
     for (int64_t i = 0; i < n; i++)
         for (int k = 0; k < 3; k++)
-            r->o[3 * i + k] = ((s->origin[k] + t[0 * n + i] * xa[k]) + t[1 * n + i] * ya[k]) + t[2 * n + i] * za[k];
+            r->o[3 * i + k] = ((origin3[k] + t[0 * n + i] * xa[k]) + t[1 * n + i] * ya[k]) + t[2 * n + i] * za[k];
 
     /* generate_direction -> make_normal (:262-266, Directed :46-50, Focused :40-44) */
     double* nv = r->nrm;
     for (int64_t i = 0; i < n; i++) {
         double a[3];
-        if (s->kind == XRT_SRC_FOCUSED)
+        if (s->kind == XRT_SRC_FOCUSED || s->kind == XRT_SRC_PLASMA)
             for (int k = 0; k < 3; k++) a[k] = s->axis[k] - r->o[3 * i + k];
         else
             for (int k = 0; k < 3; k++) a[k] = s->axis[k];
@@ -383,6 +441,39 @@ static void generate_rays(const xrt_source_t* s, mt_t* mt, rays_t* r)
         }
     }
     for (int64_t i = 0; i < n; i++) { r->wt[i] = 1.0; r->mask[i] = 1; }
+}
+
+/* sources/_XicsrtSourceGeneric.py:198 for the plain sources; for XRT_SRC_PLASMA
+ * XicsrtPlasmaGeneric.generate_rays (sources/_XicsrtPlasmaGeneric.py:384-393):
+ * setup_bundles (:176-204), then one focused source per bundle in order (:286-345) whose
+ * ray count is np.random.poisson(intensity) (_XicsrtSourceGeneric.py:191-192).
+ * Returns the number of rays generated (<= capacity r->n) or -1 on overflow. */
+static int64_t generate_rays(const xrt_source_t* s, mt_t* mt, rays_t* r)
+{
+    if (s->kind != XRT_SRC_PLASMA) {
+        generate_block(s, s->origin, mt, r, 0, r->n);
+        return r->n;
+    }
+    const int64_t B = s->bundle_count;
+    double* off = malloc(sizeof(double) * 3 * (size_t)(B > 0 ? B : 1));
+    for (int k = 0; k < 3; k++) {
+        double low = -1.0 * s->plasma_size[k] / 2.0, high = s->plasma_size[k] / 2.0;
+        fill_uniform(mt, low, high - low, off + k * B, B);
+    }
+    int64_t total = 0;
+    for (int64_t b = 0; b < B; b++) {
+        double v[3] = {off[0 * B + b], off[1 * B + b], off[2 * B + b]}, c[3];
+        to_external(s->orientation, v, c);                 /* point_to_external (:199) */
+        for (int k = 0; k < 3; k++) c[k] = c[k] + s->origin[k];
+        int64_t nb;
+        if (s->use_poisson) nb = mt_poisson(mt, s->bundle_intensity);
+        else nb = (int64_t)s->bundle_intensity;
+        if (total + nb > r->n) { free(off); return -1; }
+        generate_block(s, c, mt, r, total, nb);
+        total += nb;
+    }
+    free(off);
+    return total;
 }
 
 /* ------------------------------------------------------------------------ */
@@ -743,10 +834,10 @@ static void make_image(const xrt_optic_t* op, const rays_t* r, uint64_t* img)
     }
 }
 
-static void save_history(const rays_t* r, int e, double* hist, uint8_t* hmask)
+static void save_history(const rays_t* r, int64_t stride, int e, double* hist, uint8_t* hmask)
 {
-    const int64_t n = r->n;
-    for (int64_t i = 0; i < n; i++) {
+    const int64_t n = stride;
+    for (int64_t i = 0; i < r->n; i++) {
         hmask[(int64_t)e * n + i] = r->mask[i];
         if (!r->mask[i] && !(e > 0 && r->prev[i])) continue;   /* alive, or died at this element */
         double* h = hist + (int64_t)e * XRT_HIST_COMPONENTS * n;
@@ -764,16 +855,20 @@ static int run_single(const xrt_scene_t* sc, mt_t* mtp, int n_iter,
     rays_t r;
     if (rays_alloc(&r, sc->source.intensity)) { rays_free(&r); return -2; }
     for (int it = 0; it < n_iter; it++) {
-        generate_rays(&sc->source, &mt, &r);
+        r.n = sc->source.intensity;
+        int64_t produced = generate_rays(&sc->source, &mt, &r);
+        if (produced < 0) { rays_free(&r); return -3; }
+        const int64_t stride = r.n;
+        r.n = produced;
         num_out[0] += (uint64_t)r.n;
-        if (hist) save_history(&r, 0, hist, hmask);
+        if (hist) save_history(&r, stride, 0, hist, hmask);
         for (int e = 0; e < sc->n_optics; e++) {
             const xrt_optic_t* op = &sc->optics[e];
             trace_optic(op, &r, &mt);
             uint64_t c = 0;
             for (int64_t i = 0; i < r.n; i++) c += r.mask[i];
             num_out[e + 1] += c;
-            if (hist) save_history(&r, e + 1, hist, hmask);
+            if (hist) save_history(&r, stride, e + 1, hist, hmask);
             make_image(op, &r, images);
         }
     }

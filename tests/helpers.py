@@ -110,6 +110,7 @@ def oracle_history(flat, state):
     st = L.xrt_oracle_trace_history(flat.byref(), C.byref(state), num_out.ctypes.data, images.ctypes.data,
                                     rays.ctypes.data, mask.ctypes.data, C.byref(out))
     assert st == 0
+    n = int(mask[0].sum())      # plasma sources: drawn ray count, n_rays is the capacity
     return num_out.astype(np.int64), images.astype(np.int64), rays[:, :, :n], mask[:, :n].astype(bool), out
 
 

@@ -67,6 +67,12 @@ struct KSource {
     int32_t voigt_n;
     int32_t n_arrays;           // arrays of N doubles the source consumes (5 or 6)
     uint32_t array_used;        // bit k: values of array k are needed
+    // plasma sources (staged path only)
+    int64_t bundle_count;
+    double  plasma_low[3], plasma_range[3];
+    double  bundle_intensity;
+    double  pois[7];            // sqrt(lam), log(lam), b, a, invalpha, vr, exp(-lam) (numpy's own libm expressions)
+    int32_t use_poisson, pad2;
 };
 
 struct KOptic {
@@ -1142,6 +1148,13 @@ extern "C" int xrt_scene_check(const xrt_scene_t* sc)
         return fail(-2, "%s", "unknown angular_dist");
     if (s.wavelength_dist < XRT_WL_CONST || s.wavelength_dist > XRT_WL_VOIGT)
         return fail(-2, "%s", "unknown wavelength_dist");
+    if (s.kind < XRT_SRC_GENERIC || s.kind > XRT_SRC_PLASMA) return fail(-2, "%s", "unknown source kind");
+    if (s.kind == XRT_SRC_PLASMA) {
+        if (s.bundle_count < 1) return fail(-2, "%s", "plasma bundle_count < 1");
+        if (s.spatial_dist != XRT_SPATIAL_UNIFORM || s.angular_dist != XRT_ANG_ISOTROPIC)
+            return fail(-3, "%s", "plasma bundles support uniform voxels and isotropic cones only");
+        if (!(s.bundle_intensity >= 0.0)) return fail(-2, "%s", "bad plasma bundle intensity");
+    }
     if (s.wavelength_dist == XRT_WL_VOIGT && (s.voigt_n < 2 || !s.voigt_cdf || !s.voigt_x))
         return fail(-2, "%s", "voigt table missing");
     for (int e = 0; e < sc->n_optics; e++) {
@@ -1190,6 +1203,7 @@ static size_t ws_off_polys(const xrt_scene_t* sc, int n_runs)
 static bool needs_staged(const xrt_scene_t* sc)
 {
     const xrt_source_t& s = sc->source;
+    if (s.kind == XRT_SRC_PLASMA) return true;
     if (s.spatial_dist == XRT_SPATIAL_GAUSSIAN || s.angular_dist == XRT_ANG_ISOTROPIC_XY || s.wavelength_dist == XRT_WL_NORMAL)
         return true;
     int n_bragg = 0;
@@ -1205,7 +1219,8 @@ static size_t staged_bytes(const xrt_scene_t* sc, int n_runs)
 {
     if (!needs_staged(sc)) return 0;
     const size_t n = (size_t)(sc->source.intensity > 0 ? sc->source.intensity : 1);
-    return al256((size_t)staged_slots(n_runs) * n * (XRT_ST_ARRAYS * sizeof(double) + sizeof(uint32_t)) + 256);
+    const size_t nb = (size_t)(sc->source.bundle_count > 0 ? sc->source.bundle_count : 0);
+    return al256((size_t)staged_slots(n_runs) * (n * (XRT_ST_ARRAYS * sizeof(double) + sizeof(uint32_t)) + nb * 3 * sizeof(double)) + 256);
 }
 
 extern "C" size_t xrt_workspace_bytes(const xrt_scene_t* sc, int32_t n_runs)
@@ -1250,6 +1265,23 @@ static void build_kscene(const xrt_scene_t* sc, char* ws, KScene* k)
     d.voigt_n = s.voigt_n;
     d.voigt_cdf = reinterpret_cast<const double*>(ws + ws_off_voigt());
     d.voigt_x = d.voigt_cdf + (s.voigt_n > 0 ? s.voigt_n : 0);
+    d.bundle_count = s.bundle_count;
+    d.bundle_intensity = s.bundle_intensity;
+    d.use_poisson = s.use_poisson;
+    for (int i = 0; i < 3; i++) {
+        const double low = -1.0 * s.plasma_size[i] / 2.0, high = s.plasma_size[i] / 2.0;
+        d.plasma_low[i] = low; d.plasma_range[i] = high - low;
+    }
+    {   // constants of random_poisson_ptrs / _mult, with the host libm numpy itself uses
+        const double lam = s.bundle_intensity;
+        const double slam = sqrt(lam > 0 ? lam : 0.0), loglam = log(lam > 0 ? lam : 1.0);
+        const double b = 0.931 + 2.53 * slam;
+        const double a = -0.059 + 0.02483 * b;
+        d.pois[0] = slam; d.pois[1] = loglam; d.pois[2] = b; d.pois[3] = a;
+        d.pois[4] = 1.1239 + 1.1328 / (b - 3.4);
+        d.pois[5] = 0.9277 - 3.6224 / (b - 2);
+        d.pois[6] = exp(-lam);
+    }
     const bool wl_array = (s.wavelength_dist == XRT_WL_UNIFORM || s.wavelength_dist == XRT_WL_VOIGT);
     d.n_arrays = wl_array ? 6 : 5;
     d.array_used = 0;
@@ -1344,12 +1376,14 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
         char* base = ws + ws_off_staged(sc, n_runs);
         g.arr = reinterpret_cast<double*>(base);
         g.ids = reinterpret_cast<uint32_t*>(base + (size_t)slots * (size_t)N * XRT_ST_ARRAYS * sizeof(double));
+        g.bundle_off = reinterpret_cast<double*>(base + (size_t)slots * (size_t)N * (XRT_ST_ARRAYS * sizeof(double) + sizeof(uint32_t)));
+        g.flags = reinterpret_cast<uint32_t*>(ws) + 16;        // status word in the 256-byte workspace header
         g.gauss_state = reinterpret_cast<KState*>(ws + ws_off_gauss(sc, n_runs));
         for (int i = 0; i < 9; i++) g.spatial_A[i] = sc->source.spatial_A[i];
         g.spatial_gaussian = sc->source.spatial_dist == XRT_SPATIAL_GAUSSIAN;
         a.streams = streams; a.heads = heads; a.n_runs = n_runs; a.n_src_heads = nh;
         a.run_counter = reinterpret_cast<uint32_t*>(ws);
-        HIP_TRY(hipMemsetAsync(ws, 0, 256, stream));
+        HIP_TRY(hipMemsetAsync(ws, 0, 64, stream));
         const size_t lds = sizeof(double) * XRT_TILE_COMP * XRT_TILE + sizeof(uint32_t) * (XRT_TILE + XRT_RING + 64);
         int ti = -1;
         if (timing_on && timing_n < TIMING_MAX) {
@@ -1395,7 +1429,7 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
     }
     a.streams = streams; a.heads = heads; a.n_runs = n_runs; a.n_src_heads = nh;
     a.run_counter = reinterpret_cast<uint32_t*>(ws);
-    HIP_TRY(hipMemsetAsync(ws, 0, 256, stream));
+    HIP_TRY(hipMemsetAsync(ws, 0, 64, stream));
     const size_t lds = lds_bytes(nh);
     const bool full = needs_full(sc);
     if (hist) return full ? launch_variant<true, true>(ks, a, n_runs, lds, stream) : launch_variant<true, false>(ks, a, n_runs, lds, stream);
@@ -1428,6 +1462,7 @@ extern "C" int xrt_trace(const xrt_scene_t* sc, const uint32_t* seeds, int32_t n
     HIP_TRY(hipGetLastError());
     st = upload_tables(sc, ws, stream);
     if (st) return st;
+    HIP_TRY(hipMemsetAsync(ws + 64, 0, 64, stream));           // status word
     KScene ks;
     build_kscene(sc, ws, &ks);
     KArgs a;
@@ -1463,6 +1498,7 @@ extern "C" int xrt_trace_history(const xrt_scene_t* sc, const xrt_rng_state_t* s
     HIP_TRY(hipGetLastError());
     st = upload_tables(sc, ws, stream);
     if (st) return st;
+    HIP_TRY(hipMemsetAsync(ws + 64, 0, 64, stream));           // status word
     KScene ks;
     build_kscene(sc, ws, &ks);
     KArgs a;
@@ -1478,6 +1514,18 @@ extern "C" int xrt_trace_history(const xrt_scene_t* sc, const xrt_rng_state_t* s
                            reinterpret_cast<KState*>(state_out));
         HIP_TRY(hipGetLastError());
     }
+    return 0;
+}
+
+extern "C" int xrt_check(void* workspace, void* stream_)
+{
+    if (!workspace) return fail(-1, "%s", "NULL argument");
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    uint32_t flags = 0;
+    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(hipMemcpy(&flags, reinterpret_cast<char*>(workspace) + 64, sizeof(flags), hipMemcpyDeviceToHost));
+    if (flags & 1u)
+        return fail(-6, "%s", "plasma source produced more rays than the declared capacity (Poisson tail): results are truncated");
     return 0;
 }
 

@@ -20,12 +20,12 @@ import ctypes as C
 
 import numpy as np
 
-XRT_ABI_VERSION = 6
+XRT_ABI_VERSION = 7
 XRT_MAX_OPTICS = 16
 XRT_MAX_APERTURES = 8
 XRT_HIST_COMPONENTS = 8
 
-SRC_KIND = {'zaxis': 0, 'direction': 1, 'target': 2}
+SRC_KIND = {'zaxis': 0, 'direction': 1, 'target': 2, 'plasma': 3}
 SPATIAL = {'uniform': 0, 'gaussian': 1}
 ANGULAR = {'isotropic': 0, 'isotropic_xy': 1, 'flat': 2, 'flat_xy': 3}
 WL_CONST, WL_UNIFORM, WL_NORMAL, WL_VOIGT = 0, 1, 2, 3
@@ -57,7 +57,9 @@ class Source(C.Structure):
                 ('wl_a', C.c_double), ('wl_b', C.c_double),
                 ('has_velocity', C.c_int32), ('voigt_n', C.c_int32),
                 ('velocity', C.c_double * 3), ('light_speed', C.c_double),
-                ('voigt_cdf', C.POINTER(C.c_double)), ('voigt_x', C.POINTER(C.c_double))]
+                ('voigt_cdf', C.POINTER(C.c_double)), ('voigt_x', C.POINTER(C.c_double)),
+                ('bundle_count', C.c_int64), ('plasma_size', C.c_double * 3),
+                ('bundle_intensity', C.c_double), ('use_poisson', C.c_int32), ('pad_plasma', C.c_int32)]
 
 
 class Optic(C.Structure):
@@ -149,9 +151,74 @@ def voigt_cdf_table(gamma, sigma, gridsize=1000, cutoff=1e-5):
     return bounds[1:], cdf
 
 
+def plasma_as_source_param(obj):
+    """
+    The parameters every bundle's XicsrtSourceFocused gets from a plasma object
+    (sources/_XicsrtPlasmaGeneric.py:289-336) plus the bundle bookkeeping, for plasmas
+    whose bundles share temperature, emissivity, velocity and spread (XicsrtPlasmaCubic).
+    """
+    p = obj.param
+    if p['spread_radius'] is not None:
+        raise SceneError('plasma spread_radius (per-bundle spread) is not implemented on the device path')
+    if p['spread'] is None:
+        raise Exception('plasma spread is not set')
+    ad = 'isotropic' if p['angular_dist'] is None else str(p['angular_dist']).lower()
+    if ad != 'isotropic':
+        raise Exception(f'Solid angle calculation for "{ad}" is not available.')
+    if p['bundle_type'] == 'point':
+        voxel_size = 0.0
+    elif p['bundle_type'] == 'voxel':
+        voxel_size = p['bundle_volume'] ** (1 / 3)
+    else:
+        raise Exception('bundle_type not understood: {}'.format(p['bundle_type']))
+    B = int(p['bundle_count'])
+    # setup_bundle_spread + create_sources, per bundle (identical for every bundle here)
+    spread = np.zeros([B], dtype=np.float64)
+    spread[:] = p['spread']
+    spread_b = spread[0]
+    theta = _parse_spread_single(spread_b)
+    solid_angle = np.zeros([B], dtype=np.float64)
+    solid_angle[:] = 4 * np.pi * np.sin(theta[0] / 2) ** 2
+    emissivity = np.ones([B], dtype=np.float64)
+    emissivity[:] = p['emissivity']
+    temperature = np.ones([B], dtype=np.float64)
+    temperature[:] = p['temperature']
+    intensity = (emissivity[0] * p['time_resolution'] * p['bundle_volume'] * solid_angle[0] / (4 * np.pi))
+    intensity *= p['volume'] / (p['bundle_count'] * p['bundle_volume'])
+    predicted_rays = int(np.sum(emissivity * p['time_resolution'] * p['bundle_volume'] * solid_angle / (4 * np.pi)
+                                * p['volume'] / (p['bundle_count'] * p['bundle_volume'])))
+    if p['max_rays']:
+        if predicted_rays > p['max_rays']:
+            raise ValueError(f"Current settings will produce too many rays ({predicted_rays:0.2e}). "
+                             f"Please reduce integration time or adjust other parameters.")
+    if p['use_poisson']:
+        capacity = int(predicted_rays + 12 * np.sqrt(max(predicted_rays, 1)) + 4096)
+    else:
+        if intensity < 1:
+            raise ValueError('intensity of less than one encountered. Turn on poisson statistics.')
+        capacity = B * int(intensity)
+    q = {'xsize': voxel_size, 'ysize': voxel_size, 'zsize': voxel_size, 'spatial_dist': 'uniform',
+         'angular_dist': ad, 'spread': spread_b, 'intensity': capacity, 'zaxis': p['zaxis'], 'xaxis': p['xaxis'],
+         'wavelength_dist': p['wavelength_dist'], 'wavelength': p['wavelength'],
+         'wavelength_range': p['wavelength_range'], 'linewidth': p['linewidth'], 'mass_number': p['mass_number'],
+         'temperature': temperature[0], 'velocity': np.zeros(3), 'target': p['target']}
+    return q, B, float(intensity)
+
+
 def flatten_source(obj, out, keep):
     """Fill a Source struct from an initialised XicsrtSource* object; `keep` pins host arrays."""
     p = obj.param
+    out.bundle_count = 0
+    _vec(out.plasma_size, np.zeros(3))
+    out.bundle_intensity = 0.0
+    out.use_poisson = 0
+    if obj.cone_axis_rule == 'plasma':
+        q, B, lam = plasma_as_source_param(obj)
+        out.bundle_count = B
+        _vec(out.plasma_size, [p['xsize'], p['ysize'], p['zsize']])
+        out.bundle_intensity = lam
+        out.use_poisson = int(bool(p['use_poisson']))
+        p = q
     out.kind = SRC_KIND[obj.cone_axis_rule]
     sd = str(p['spatial_dist'])
     if sd not in SPATIAL:
@@ -176,12 +243,12 @@ def flatten_source(obj, out, keep):
         # legacy multivariate_normal: x = standard_normal @ (sqrt(s)[:, None] * v)
         (u, s, v) = np.linalg.svd(cov.astype(np.double))
         _vec(out.spatial_A, np.sqrt(s)[:, None] * v)
-    axis = obj.cone_axis()
+    axis = p['target'] if obj.cone_axis_rule == 'plasma' else obj.cone_axis()
     if axis is None:
         raise Exception('source cone axis (%s) is not set' % obj.cone_axis_rule)
     _vec(out.axis, axis)
     _vec(out.basis, np.zeros(9))
-    if obj.cone_axis_rule != 'target':
+    if obj.cone_axis_rule not in ('target', 'plasma'):
         # make_normal + random_direction frame for a single (shared) cone axis
         array = np.empty((1, 3))
         array[:] = axis

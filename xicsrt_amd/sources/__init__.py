@@ -110,4 +110,80 @@ class XicsrtSourceFocused(XicsrtSourceGeneric):
         return self.param['target']
 
 
-BUILTIN = {cls.__name__: cls for cls in (XicsrtSourceGeneric, XicsrtSourceDirected, XicsrtSourceFocused)}
+class XicsrtPlasmaGeneric(GeometryObject):
+    """
+    A plasma volume emitting from randomly placed bundles; every bundle is an
+    XicsrtSourceFocused aimed at `target` whose ray count follows the local
+    emissivity (sources/_XicsrtPlasmaGeneric.py:21-393).  Config keys and the
+    bundle bookkeeping of the reference; sampling runs on the device.
+    """
+
+    cone_axis_rule = 'plasma'
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.filter_objects = []
+
+    def default_config(self):
+        """
+        xsize, ysize, zsize, target, spread / spread_radius, angular_dist,
+        emissivity [photons/s/m^3], temperature [eV], velocity, time_resolution [s],
+        bundle_type ('voxel' | 'point'), bundle_volume, bundle_count, max_rays, max_bundles,
+        use_poisson, wavelength_dist, wavelength, wavelength_range, mass_number, linewidth, filters
+        """
+        config = super().default_config()
+        config['xsize'] = 0.0
+        config['ysize'] = 0.0
+        config['zsize'] = 0.0
+        config['angular_dist'] = 'isotropic'
+        config['spread'] = None
+        config['spread_radius'] = None
+        config['target'] = None
+        config['use_poisson'] = False
+        config['wavelength_dist'] = 'voigt'
+        config['wavelength'] = 1.0
+        config['wavelength_range'] = None
+        config['mass_number'] = 1.0
+        config['linewidth'] = 0.0
+        config['emissivity'] = 0.0
+        config['temperature'] = 0.0
+        config['velocity'] = 0.0
+        config['time_resolution'] = 1e-3
+        config['bundle_type'] = 'voxel'
+        config['bundle_volume'] = 1e-6
+        config['bundle_count'] = None
+        config['max_rays'] = int(1e7)
+        config['max_bundles'] = int(1e7)
+        config['filters'] = []
+        return config
+
+    def initialize(self):
+        super().initialize()
+        p = self.param
+        if p['max_rays'] is not None:
+            p['max_rays'] = int(p['max_rays'])
+        p['volume'] = self.config['xsize'] * self.config['ysize'] * self.config['zsize']
+        if p['bundle_count'] is None:
+            p['bundle_count'] = p['volume'] / p['bundle_volume']
+        p['bundle_count'] = int(np.round(p['bundle_count']))
+        if p['bundle_count'] < 1:
+            raise Exception(f'Bundle volume is larger than the plasma volume.')
+        if p['bundle_count'] > p['max_bundles']:
+            raise ValueError(
+                f"Current settings will produce too many bundles ({p['bundle_count']:0.2e}). "
+                f"Increase the bundle_volume, explicitly set bundle_count or increase max_bundles.")
+
+    def cone_axis(self):
+        return self.param['target']
+
+    def generate_rays(self):
+        from .. import xicsrt_raytrace as _rt
+        return _rt.generate_rays_from_global_state(self)
+
+
+class XicsrtPlasmaCubic(XicsrtPlasmaGeneric):
+    """A cuboid plasma with constant temperature and emissivity (sources/_XicsrtPlasmaCubic.py:16-35)."""
+
+
+BUILTIN = {cls.__name__: cls for cls in (XicsrtSourceGeneric, XicsrtSourceDirected, XicsrtSourceFocused,
+                                         XicsrtPlasmaGeneric, XicsrtPlasmaCubic)}

@@ -72,7 +72,7 @@ def find_class(class_name, section, pathlist):
             mod = importlib.util.module_from_spec(spec)
             spec.loader.exec_module(mod)
             cls = getattr(mod, class_name)
-            base = _sources.XicsrtSourceGeneric if section == 'sources' else _optics.TraceObject
+            base = (_sources.XicsrtSourceGeneric, _sources.XicsrtPlasmaGeneric) if section == 'sources' else _optics.TraceObject
             if not issubclass(cls, base):
                 raise NotImplementedError(
                     'User plug-in %s (%s) is not built from xicsrt_amd element classes; arbitrary NumPy '
@@ -258,10 +258,15 @@ class DeviceTrace:
         t.cuda.current_stream().synchronize()
         out = xscene.RngState.from_buffer_copy(st_out.cpu().numpy().tobytes())
         state_out = (np.ctypeslib.as_array(out.key).copy(), int(out.pos), int(out.has_gauss), float(out.gauss))
-        return rays.cpu().numpy()[:, :, :n], mask.cpu().numpy()[:, :n].astype(bool), state_out
+        mask_h = mask.cpu().numpy()[:, :n].astype(bool)
+        n = int(mask_h[0].sum())        # plasma sources: the ray count is drawn, n_rays is the capacity
+        return rays.cpu().numpy()[:, :, :n], mask_h[:, :n], state_out
 
     def results(self):
         """Host copies (synchronises the stream): num_out list, {optic: image or None}."""
+        if self._ws is not None:
+            self.capi.check(self.lib.xrt_check(self._ws.data_ptr(), self.torch.cuda.current_stream().cuda_stream),
+                            'xrt_check')
         self.torch.cuda.current_stream().synchronize()
         return self.unpack(self.num_out.cpu().numpy(), self.images.cpu().numpy())
 
