@@ -1,0 +1,160 @@
+"""
+GPU tests at and near BASELINE sizes (-m gpu): where the oracle is too slow to follow, parity
+is carried by size-independent properties of the domain (exact integer sums, partition and
+repetition invariance, histogram = counter identities).
+"""
+import copy
+
+import numpy as np
+import pytest
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def _spectrometer(n_rays, runs, seed=0, **optic_over):
+    cfg, _ = helpers.load_golden('C_sphere_1e5')
+    cfg = copy.deepcopy(cfg)
+    cfg['sources']['source']['intensity'] = n_rays
+    cfg['general'].update(number_of_runs=runs, random_seed=seed)
+    cfg['optics']['crystal'].update(optic_over)
+    return cfg
+
+
+def _trace(flat, seeds, n_iter=1):
+    from xicsrt_amd import xicsrt_raytrace as xrt
+    dev = xrt.DeviceTrace(flat)
+    dev.trace(seeds, n_iter)
+    dev.torch.cuda.synchronize()
+    return dev.num_out.cpu().numpy().copy(), dev.images.cpu().numpy().copy()
+
+
+def test_million_ray_runs_equal_oracle_bit_for_bit():
+    """16 runs x 1e6 rays of the bench scene: counters and both images identical to the CPU oracle."""
+    from xicsrt_amd import xicsrt_raytrace as xrt
+    config, elements, flat = helpers.build(_spectrometer(1000000, 16, seed=123))
+    seeds = xrt.run_seeds(123, 16)
+    n_gpu, i_gpu = _trace(flat, seeds)
+    n_cpu, i_cpu = helpers.oracle_counts(flat, seeds, 1, threads=16)
+    assert np.array_equal(n_gpu, n_cpu)
+    assert np.array_equal(i_gpu[:flat.image_bins], i_cpu[:flat.image_bins])
+    assert int(n_gpu[0]) == 16000000 and 0.040 < n_gpu[2] / n_gpu[0] < 0.044
+
+
+def test_full_size_invariants_1e9_photons():
+    """The bench workload itself (1000 runs x 1e6 rays): exact identities that do not need an oracle."""
+    from xicsrt_amd import xicsrt_raytrace as xrt
+    config, elements, flat = helpers.build(_spectrometer(1000000, 1000))
+    seeds = xrt.run_seeds(0, 1000)
+    n_all, i_all = _trace(flat, seeds)
+    assert int(n_all[0]) == 10 ** 9
+    off_c, nx_c, ny_c = flat.image_slices['crystal']
+    off_d, nx_d, ny_d = flat.image_slices['detector']
+    # every reflected ray is binned on the crystal image, every detector hit on the detector image
+    assert int(i_all[off_c:off_c + nx_c * ny_c].sum()) == int(n_all[1])
+    assert int(i_all[off_d:off_d + nx_d * ny_d].sum()) == int(n_all[2])
+    # repetition: the same launch again gives the same integers (atomics commute exactly)
+    n_again, i_again = _trace(flat, seeds)
+    assert np.array_equal(n_all, n_again) and np.array_equal(i_all, i_again)
+    # partition: three unequal shards of the runs sum to the whole (what the multi-GPU path relies on)
+    parts = [seeds[0:100], seeds[100:617], seeds[617:]]
+    n_sum = np.zeros_like(n_all)
+    i_sum = np.zeros_like(i_all)
+    for p in parts:
+        n, i = _trace(flat, p)
+        n_sum += n
+        i_sum += i
+    assert np.array_equal(n_sum, n_all) and np.array_equal(i_sum, i_all)
+    # the first 8 runs of the 1e9-photon job equal the reference's own published count for
+    # 8 x 1e6 photons, seed 0 (335 789 detector hits)
+    n8, _ = _trace(flat, seeds[:8])
+    assert int(n8[2]) == 335789 and int(n8[1]) == 335789
+
+
+def test_iterations_chain_the_stream():
+    """number_of_iter=3 equals one iteration thrice only through the shared stream: compare with the oracle."""
+    from xicsrt_amd import xicsrt_raytrace as xrt
+    config, elements, flat = helpers.build(_spectrometer(200000, 6, seed=9))
+    seeds = xrt.run_seeds(9, 6)
+    n_gpu, i_gpu = _trace(flat, seeds, n_iter=3)
+    n_cpu, i_cpu = helpers.oracle_counts(flat, seeds, 3, threads=6)
+    assert np.array_equal(n_gpu, n_cpu) and np.array_equal(i_gpu[:flat.image_bins], i_cpu[:flat.image_bins])
+
+
+def _random_scene(rs):
+    """A random 3- or 4-element scene from the implemented classes (geometry of integrated_test_01, jittered)."""
+    optic_classes = [
+        ('XicsrtOpticPlanarMirror', {}), ('XicsrtOpticSphericalMirror', {'radius': 1.0}),
+        ('XicsrtOpticPlanarCrystal', 'bragg'), ('XicsrtOpticSphericalCrystal', 'bragg+r'),
+        ('XicsrtOpticCylindricalCrystal', 'bragg+r'), ('XicsrtOpticCylindricalMirror', {'radius': 1.0}),
+        ('XicsrtOpticToroidalCrystal', 'bragg+t')]
+    cls, extra = optic_classes[rs.randint(len(optic_classes))]
+    crystal = {'class_name': cls, 'origin': [0.0, 0.0, 0.80374151], 'zaxis': [0.0, 0.59497864, -0.80374151],
+               'xsize': float(rs.uniform(0.05, 0.3)), 'ysize': float(rs.uniform(0.05, 0.3))}
+    if isinstance(extra, dict):
+        crystal.update(extra)
+        if rs.rand() < 0.3 and 'radius' in extra:
+            crystal['convex'] = True
+    else:
+        crystal.update(crystal_spacing=2.45676, rocking_type=['gaussian', 'step'][rs.randint(2)],
+                       rocking_fwhm=float(10 ** rs.uniform(-4.3, -2.0)), reflectivity=float(rs.uniform(0.3, 1.0)))
+        if rs.rand() < 0.25:
+            crystal['check_bragg'] = False
+        if '+r' in extra:
+            crystal['radius'] = float(rs.uniform(0.8, 1.5))
+        if '+t' in extra:
+            crystal.update(radius_major=float(rs.uniform(0.9, 1.3)), radius_minor=float(rs.uniform(0.1, 0.4)))
+    if rs.rand() < 0.3:
+        crystal['aperture'] = [{'shape': 'circle', 'size': [float(rs.uniform(0.03, 0.12))]},
+                               {'shape': 'rectangle', 'size': [0.04, 0.02], 'origin': [0.01, -0.01],
+                                'logic': ['not', 'or', 'xor'][rs.randint(3)]}]
+    source = {'class_name': ['XicsrtSourceDirected', 'XicsrtSourceGeneric', 'XicsrtSourceFocused'][rs.randint(3)],
+              'intensity': int(rs.randint(3000, 9000)), 'wavelength': 3.9492,
+              'spread': float(np.radians(rs.uniform(2.0, 12.0))),
+              'xsize': float(rs.choice([0.0, 0.002])), 'ysize': float(rs.choice([0.0, 0.004])), 'zsize': 0.0}
+    if source['class_name'] == 'XicsrtSourceFocused':
+        source['target'] = [0.0, 0.0, 0.80374151]
+    wl = rs.randint(4)
+    if wl == 1:
+        source.update(wavelength_dist='uniform', wavelength_range=[3.9480, 3.9500])
+    elif wl == 2:
+        source.update(temperature=float(rs.uniform(200, 2000)), mass_number=39.948)
+    elif wl == 3:
+        source.update(linewidth=1.129e14, temperature=1000.0, mass_number=39.948)
+    if rs.rand() < 0.25:
+        source['angular_dist'] = ['flat', 'flat_xy', 'isotropic_xy'][rs.randint(3)]
+        if source['angular_dist'] != 'flat':
+            source['spread'] = [float(rs.uniform(0.03, 0.12)), float(rs.uniform(0.03, 0.12))]
+    cfg = {'general': {'number_of_iter': int(rs.randint(1, 3)), 'number_of_runs': int(rs.randint(1, 4)),
+                       'random_seed': int(rs.randint(0, 2 ** 31)), 'keep_history': False, 'print_results': False},
+           'sources': {'source': source},
+           'optics': {'crystal': crystal,
+                      'detector': {'class_name': 'XicsrtOpticDetector', 'origin': [0.0, 0.76871290, 0.56904832],
+                                   'zaxis': [0.0, -0.95641806, 0.29200084], 'xsize': 0.4, 'ysize': 0.2}}}
+    return cfg
+
+
+@pytest.mark.parametrize('case', range(24))
+def test_random_scenes_equal_oracle(case):
+    """Randomised sources / optics / seeds: device == oracle exactly (counts, images) and in history."""
+    from xicsrt_amd import xicsrt_raytrace as xrt
+    rs = np.random.RandomState(1000 + case)
+    cfg = _random_scene(rs)
+    config, elements, flat = helpers.build(cfg)
+    g = config['general']
+    seeds = xrt.run_seeds(g['random_seed'], g['number_of_runs'])
+    n_gpu, i_gpu = _trace(flat, seeds, g['number_of_iter'])
+    n_cpu, i_cpu = helpers.oracle_counts(flat, seeds, g['number_of_iter'])
+    assert np.array_equal(n_gpu, n_cpu), (cfg, n_gpu, n_cpu)
+    assert np.array_equal(i_gpu[:flat.image_bins], i_cpu[:flat.image_bins])
+    dev = xrt.DeviceTrace(flat)
+    rays, mask, st = dev.trace_history(xrt.rng_state_from_seed(seeds[0]))
+    o_num, o_img, o_rays, o_mask, o_st = helpers.oracle_history(flat, helpers.seed_state(seeds[0]))
+    assert np.array_equal(mask, o_mask)
+    assert np.array_equal(np.isnan(rays), np.isnan(o_rays))
+    ok = ~np.isnan(o_rays)
+    assert np.max(np.abs(rays[ok] - o_rays[ok])) <= 1e-12 * max(1.0, np.max(np.abs(o_rays[ok])))
+    rs2 = np.random.RandomState(0)
+    rs2.set_state(('MT19937',) + tuple(st))
+    assert rs2.random_sample() == helpers.state_next_double(o_st)
