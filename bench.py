@@ -113,7 +113,9 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
+    # XICSRT_BENCH_FORCE_DIST=1 exercises the RCCL path with a single rank (launched through torchrun)
+    use_dist = world > 1 or (os.environ.get('XICSRT_BENCH_FORCE_DIST') == '1' and 'RANK' in os.environ)
+    if use_dist:
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
     else:
@@ -132,14 +134,14 @@ def main():
         dev.num_out.zero_()
         dev.images.zero_()
         dev.trace(my_seeds, 1, keep_images=True)
-        if world > 1:
+        if use_dist:
             packed = torch.cat([dev.num_out, dev.images])
             dist.all_reduce(packed, op=dist.ReduceOp.SUM)
             return packed
         return dev.num_out
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -155,7 +157,7 @@ def main():
     kernel_ms = C.c_double(0.0)
     launches = C.c_int64(0)
     lib.xrt_timing_end(C.byref(kernel_ms), C.byref(launches))
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -192,7 +194,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(flat, args.rays)
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

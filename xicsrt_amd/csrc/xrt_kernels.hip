@@ -44,6 +44,7 @@
 #define XRT_AHEAD    512u       // words every head keeps generated ahead of its read position
 #define XRT_STRETCH  20560      // 19937 + 623 words: what one jump reads
 #define XRT_TILE_COMP 7         // x,y,z, dx,dy,dz, wavelength
+#define XRT_QCAP     384u       // records in the fused kernel's circular ray buffer (127 queued + 256 new)
 
 // --------------------------------------------------------------------------
 // kernel-argument scene (passed by value: uniform, read through scalar loads)
@@ -859,9 +860,13 @@ __global__ __launch_bounds__(XRT_TILE, XRT_WAVES_PER_EU)
 void xrt_trace_kernel(const KScene sc, const KArgs args)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    double*   tile   = reinterpret_cast<double*>(lds_raw);                             // [10][256]
-    uint32_t* tileid = reinterpret_cast<uint32_t*>(tile + XRT_TILE_COMP * XRT_TILE);   // [256]
-    uint32_t* rings  = tileid + XRT_TILE;                                              // [nh+1][1024]
+    // One circular structure-of-arrays buffer of XRT_QCAP ray records serves as
+    //  (a) the FIFO queue of rays waiting for the Bragg test (filled tile by tile in ray
+    //      order, drained 128 at a time so that the test always runs on two full waves), and
+    //  (b) scratch for the stable compactions between the other elements (its free part).
+    double*   qbuf   = reinterpret_cast<double*>(lds_raw);                             // [7][XRT_QCAP]
+    uint32_t* qid    = reinterpret_cast<uint32_t*>(qbuf + XRT_TILE_COMP * XRT_QCAP);   // [XRT_QCAP]
+    uint32_t* rings  = qid + XRT_QCAP;                                                 // [nh+1][1024]
     const int tid = threadIdx.x;
     const KSource& S = sc.src;
     const int64_t N = S.n_rays;
@@ -873,6 +878,25 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
     uint32_t* bcast = small + 8 + 2 * (XRT_DEV_MAX_OPTICS + 2);
 
     int slot = 0;
+
+    // the (single) element that makes a Bragg test on this path, or -1
+    int be = -1;
+    for (int e = 0; e < sc.n_optics; e++)
+        if (sc.opt[e].interact == XRT_INTERACT_CRYSTAL && (sc.opt[e].flags & XRT_F_CHECK_BRAGG)) be = e;
+
+    auto q_store = [&](uint32_t i, const V3& o, const V3& d, double wl, uint32_t id) {
+        qbuf[0 * XRT_QCAP + i] = o.x; qbuf[1 * XRT_QCAP + i] = o.y; qbuf[2 * XRT_QCAP + i] = o.z;
+        qbuf[3 * XRT_QCAP + i] = d.x; qbuf[4 * XRT_QCAP + i] = d.y; qbuf[5 * XRT_QCAP + i] = d.z;
+        qbuf[6 * XRT_QCAP + i] = wl;
+        qid[i] = id;
+    };
+    auto q_load = [&](uint32_t i, V3& o, V3& d, double& wl, uint32_t& id) {
+        o.x = qbuf[0 * XRT_QCAP + i]; o.y = qbuf[1 * XRT_QCAP + i]; o.z = qbuf[2 * XRT_QCAP + i];
+        d.x = qbuf[3 * XRT_QCAP + i]; d.y = qbuf[4 * XRT_QCAP + i]; d.z = qbuf[5 * XRT_QCAP + i];
+        wl = qbuf[6 * XRT_QCAP + i];
+        id = qid[i];
+    };
+    auto q_wrap = [](uint32_t i) -> uint32_t { return i >= XRT_QCAP ? i - XRT_QCAP : i; };
 
     for (;;) {
         // ---- next run ------------------------------------------------------
@@ -906,21 +930,22 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
         const uint64_t s_next0 = uni64(st->next), s_gen0 = uni64(st->gen);
         uint32_t sgen = (uint32_t)s_gen0, spos = (uint32_t)s_next0;
         uint64_t s_used = 0;
+        uint32_t qhead = 0, qcount = 0;
         if (tid < XRT_DEV_MAX_OPTICS + 1) cnt[tid] = 0ULL;
         __syncthreads();
 
         // One generation step: every head (and the stream head) that has fewer
         // than 512 words ready extends its window by at most 227 words.  Steps
         // must be separated by a barrier; they are placed in front of barriers
-        // the tile needs anyway.  Returns whether anything is still short.
+        // the tile needs anyway.
         auto mt_step = [&]() {
             int h = 0;
 #pragma unroll
             for (int k = 0; k < 6; k++) {
                 if ((S.array_used >> k) & 1u) {
                     uint32_t avail = hgen[k] - hpos[k];
-                    if (avail < 512u) {
-                        uint32_t chunk = 512u - avail;
+                    if (avail < XRT_AHEAD) {
+                        uint32_t chunk = XRT_AHEAD - avail;
                         if (chunk > 227u) chunk = 227u;
                         if ((uint32_t)tid < chunk) {
                             uint32_t* r = rings + h * XRT_RING;
@@ -934,8 +959,8 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
                 }
             }
             uint32_t avail = sgen - spos;
-            if (avail < 512u) {
-                uint32_t chunk = 512u - avail;
+            if (avail < XRT_AHEAD) {
+                uint32_t chunk = XRT_AHEAD - avail;
                 if (chunk > 227u) chunk = 227u;
                 if ((uint32_t)tid < chunk) {
                     uint32_t n = sgen + (uint32_t)tid;
@@ -945,30 +970,87 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
                 sgen += chunk;
             }
         };
-        auto mt_short = [&]() -> bool {
-            bool s = (sgen - spos) < 512u;
+        auto heads_short = [&]() -> bool {
+            bool sh = false;
 #pragma unroll
             for (int k = 0; k < 6; k++)
-                if ((S.array_used >> k) & 1u) s = s || ((hgen[k] - hpos[k]) < 512u);
-            return s;
+                if ((S.array_used >> k) & 1u) sh = sh || ((hgen[k] - hpos[k]) < XRT_AHEAD);
+            return sh;
         };
 
         // Bragg angle shared by all rays when the wavelength is one constant
         const bool wl_shared = (S.wavelength_dist == XRT_WL_CONST) && !S.has_velocity;
         double bragg_shared = 0.0;
-        if (wl_shared)
-            for (int e = 0; e < sc.n_optics; e++)
-                if (sc.opt[e].interact == XRT_INTERACT_CRYSTAL && (sc.opt[e].flags & XRT_F_CHECK_BRAGG))
-                    bragg_shared = asin((1.0 * S.wavelength) / sc.opt[e].two_d);
+        if (wl_shared && be >= 0) bragg_shared = asin((1.0 * S.wavelength) / sc.opt[be].two_d);
+
+        // Elements without a Bragg test, starting at element `e` with rays held by the threads
+        // tid < n_in (`fresh` = the rays still have to be intersected with element e; otherwise
+        // `alive` already says which of them left element e).  Runs up to (not including) the
+        // Bragg element, where it returns true with the candidates' state for the caller to queue.
+        // `scratch`: first free record of the circular buffer, used for the compactions.
+        auto plain_elements = [&](int e, bool fresh, uint32_t n_in, bool& have, bool& alive, Ray& ray, V3& X,
+                                  uint32_t& id, uint32_t scratch) -> int {
+            for (; e < sc.n_optics && n_in > 0; e++) {
+                const KOptic& op = sc.opt[e];
+                if (fresh) {
+                    alive = false;
+                    if (have) {
+                        bool hit = intersect_point<FULL>(op, ray, X);
+                        alive = hit && check_bounds<FULL>(op, X);
+                        if (HIST && !alive) {
+                            V3 xo = X;
+                            if (!hit) { xo.x = xo.y = xo.z = __builtin_nan(""); }
+                            hist_write(args.hist, args.hmask, N, e + 1, id, xo, ray.d, ray.wl, false);
+                        }
+                    }
+                    if (e == be) return e;                       // candidates for the Bragg queue
+                    // InteractObject / InteractMirror.reflect_vectors (optics/_InteractMirror.py:29-42)
+                    if (alive) {
+                        ray.o = X;
+                        if (op.interact != XRT_INTERACT_NONE) {
+                            V3 nrm = surface_normal<FULL>(op, X);
+                            double dt = dot_e(ray.d, nrm);
+                            ray.d.x = ray.d.x - 2.0 * (dt * nrm.x);
+                            ray.d.y = ray.d.y - 2.0 * (dt * nrm.y);
+                            ray.d.z = ray.d.z - 2.0 * (dt * nrm.z);
+                        }
+                        if (HIST) hist_write(args.hist, args.hmask, N, e + 1, id, ray.o, ray.d, ray.wl, true);
+                    }
+                }
+                fresh = true;
+                // stable compaction of the survivors for the next element; the pixel of element e
+                // is found after it, on dense lanes
+                uint32_t n_out;
+                mt_step();
+                uint32_t rank = wg_rank(alive, wave_tot, slot, tid, n_out);
+                if (tid == 0) cnt[e + 1] += n_out;
+                const bool image = (op.flags & XRT_F_IMAGE) && args.images;
+                if (e + 1 < sc.n_optics && n_out > 0) {
+                    if (alive) q_store(q_wrap(scratch + rank), ray.o, ray.d, ray.wl, id);
+                    mt_step();
+                    __syncthreads();
+                    have = (uint32_t)tid < n_out;
+                    if (have) {
+                        q_load(q_wrap(scratch + (uint32_t)tid), ray.o, ray.d, ray.wl, id);
+                        if (image) image_hit(op, ray.o, args.images);
+                    }
+                    // the next write into the buffer happens behind the next scan's barrier
+                } else if (image && alive) {
+                    image_hit(op, ray.o, args.images);
+                }
+                n_in = n_out;
+            }
+            return -1;
+        };
 
         // ---- tiles of 256 rays in original order ----------------------------
         for (int64_t i0 = 0; i0 < N; i0 += XRT_TILE) {
             const int64_t left = N - i0;
-            uint32_t n_in = left < XRT_TILE ? (uint32_t)left : (uint32_t)XRT_TILE;
+            const uint32_t n_tile = left < XRT_TILE ? (uint32_t)left : (uint32_t)XRT_TILE;
 
             // everything this tile consumes must be generated: normally already
             // done behind the previous tile's barriers
-            while (mt_short()) { mt_step(); __syncthreads(); }
+            while (heads_short()) { mt_step(); __syncthreads(); }
 
             double u[6];
             {
@@ -980,102 +1062,65 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
                         const uint32_t* r = rings + h * XRT_RING;
                         uint32_t n = hpos[k] + 2u * (uint32_t)tid;
                         u[k] = mt_double(r[n & XRT_RMASK], r[(n + 1u) & XRT_RMASK]);
-                        hpos[k] += 512u;
+                        hpos[k] += XRT_AHEAD;
                         h++;
                     }
                 }
             }
 
             Ray ray;
+            V3 X;
+            X.x = X.y = X.z = 0.0;
             uint32_t id = (uint32_t)(i0 + tid);
-            bool have = (uint32_t)tid < n_in;
+            bool have = (uint32_t)tid < n_tile, alive = false;
             source_ray<FULL>(S, u, ray);
-            if (tid == 0) cnt[0] += n_in;
+            if (tid == 0) cnt[0] += n_tile;
             if (HIST && have) hist_write(args.hist, args.hmask, N, 0, id, ray.o, ray.d, ray.wl, true);
 
-            // ---- optics in config order (objects/_Dispatcher.py:166-196) ------
-            for (int e = 0; e < sc.n_optics && n_in > 0; e++) {
-                const KOptic& op = sc.opt[e];
-                V3 X, nrm;
-                X.x = X.y = X.z = 0.0; nrm = X;
-                bool alive = false;
+            // elements in config order (objects/_Dispatcher.py:166-196) up to the Bragg element
+            const int stop = plain_elements(0, true, n_tile, have, alive, ray, X, id, q_wrap(qhead + qcount));
+            if (stop >= 0) {
+                // queue the candidates in ray order: ordered live rank -> FIFO position
+                uint32_t n_a;
+                mt_step();
+                uint32_t rank = wg_rank(alive, wave_tot, slot, tid, n_a);
+                if (alive) q_store(q_wrap(qhead + qcount + rank), X, ray.d, ray.wl, id);
+                qcount += n_a;
+            }
+
+            // ---- Bragg test + the remaining elements, 128 queued rays at a time -----------
+            const bool last_tile = (i0 + XRT_TILE >= N);
+            while (be >= 0 && (qcount >= 128u || (last_tile && qcount > 0u))) {
+                const KOptic& op = sc.opt[be];
+                const uint32_t nb = qcount < 128u ? qcount : 128u;
+                // n uniforms from the stream head (np.random.uniform(0,1,n_live), optics/_InteractCrystal.py:189)
+                while ((sgen - spos) < 2u * nb) { mt_step(); __syncthreads(); }
+                mt_step();
+                __syncthreads();                                  // queue records visible
+                have = (uint32_t)tid < nb;
+                alive = false;
                 if (have) {
-                    bool hit = intersect_point<FULL>(op, ray, X);
-                    alive = hit && check_bounds<FULL>(op, X);
-                    if (HIST && !alive) {
-                        V3 xo = X;
-                        if (!hit) { xo.x = xo.y = xo.z = __builtin_nan(""); }
-                        hist_write(args.hist, args.hmask, N, e + 1, id, xo, ray.d, ray.wl, false);
-                    }
-                }
-                const bool bragg = (op.interact == XRT_INTERACT_CRYSTAL) && (op.flags & XRT_F_CHECK_BRAGG);
-                if (bragg) {
-                    // ordered live rank -> index of the ray's uniform in the stream
-                    uint32_t n_a;
-                    mt_step();
-                    uint32_t rank = wg_rank(alive, wave_tot, slot, tid, n_a);
+                    q_load(q_wrap(qhead + (uint32_t)tid), X, ray.d, ray.wl, id);
+                    V3 nrm = surface_normal<FULL>(op, X);
+                    uint32_t n = spos + 2u * (uint32_t)tid;
+                    double test = 0.0 + (1.0 - 0.0) * mt_double(stream[n & XRT_RMASK], stream[(n + 1u) & XRT_RMASK]);
+                    alive = bragg_accept(op, ray, nrm, test, wl_shared, bragg_shared);
+                    if (HIST && !alive) hist_write(args.hist, args.hmask, N, be + 1, id, X, ray.d, ray.wl, false);
                     if (alive) {
-                        tile[0 * XRT_TILE + rank] = X.x;     tile[1 * XRT_TILE + rank] = X.y;     tile[2 * XRT_TILE + rank] = X.z;
-                        tile[3 * XRT_TILE + rank] = ray.d.x; tile[4 * XRT_TILE + rank] = ray.d.y; tile[5 * XRT_TILE + rank] = ray.d.z;
-                        tile[6 * XRT_TILE + rank] = ray.wl;
-                        tileid[rank] = id;
-                    }
-                    mt_step();
-                    __syncthreads();
-                    have = (uint32_t)tid < n_a;
-                    alive = false;
-                    if (have) {
-                        X.x = tile[0 * XRT_TILE + tid];     X.y = tile[1 * XRT_TILE + tid];     X.z = tile[2 * XRT_TILE + tid];
-                        ray.d.x = tile[3 * XRT_TILE + tid]; ray.d.y = tile[4 * XRT_TILE + tid]; ray.d.z = tile[5 * XRT_TILE + tid];
-                        ray.wl = tile[6 * XRT_TILE + tid];
-                        id = tileid[tid];
-                        nrm = surface_normal<FULL>(op, X);
-                        // np.random.uniform(0, 1, n_live)[rank] (optics/_InteractCrystal.py:189)
-                        uint32_t n = spos + 2u * (uint32_t)tid;
-                        double test = 0.0 + (1.0 - 0.0) * mt_double(stream[n & XRT_RMASK], stream[(n + 1u) & XRT_RMASK]);
-                        alive = bragg_accept(op, ray, nrm, test, wl_shared, bragg_shared);
-                        if (HIST && !alive) hist_write(args.hist, args.hmask, N, e + 1, id, X, ray.d, ray.wl, false);
-                    }
-                    spos += 2u * n_a;
-                    s_used += 2ull * n_a;
-                }
-                // InteractObject / InteractMirror.reflect_vectors (optics/_InteractMirror.py:29-42)
-                if (alive) {
-                    ray.o = X;
-                    if (op.interact != XRT_INTERACT_NONE) {
-                        if (!bragg) nrm = surface_normal<FULL>(op, X);
+                        ray.o = X;
                         double dt = dot_e(ray.d, nrm);
                         ray.d.x = ray.d.x - 2.0 * (dt * nrm.x);
                         ray.d.y = ray.d.y - 2.0 * (dt * nrm.y);
                         ray.d.z = ray.d.z - 2.0 * (dt * nrm.z);
+                        if (HIST) hist_write(args.hist, args.hmask, N, be + 1, id, ray.o, ray.d, ray.wl, true);
                     }
-                    if ((op.flags & XRT_F_IMAGE) && args.images) image_hit(op, X, args.images);
-                    if (HIST) hist_write(args.hist, args.hmask, N, e + 1, id, ray.o, ray.d, ray.wl, true);
                 }
-                // stable compaction of the survivors for the next element
-                uint32_t n_out;
-                mt_step();
-                uint32_t rank = wg_rank(alive, wave_tot, slot, tid, n_out);
-                if (tid == 0) cnt[e + 1] += n_out;
-                if (e + 1 < sc.n_optics && n_out > 0) {
-                    if (alive) {
-                        tile[0 * XRT_TILE + rank] = ray.o.x; tile[1 * XRT_TILE + rank] = ray.o.y; tile[2 * XRT_TILE + rank] = ray.o.z;
-                        tile[3 * XRT_TILE + rank] = ray.d.x; tile[4 * XRT_TILE + rank] = ray.d.y; tile[5 * XRT_TILE + rank] = ray.d.z;
-                        tile[6 * XRT_TILE + rank] = ray.wl;
-                        tileid[rank] = id;
-                    }
-                    mt_step();
-                    __syncthreads();
-                    have = (uint32_t)tid < n_out;
-                    if (have) {
-                        ray.o.x = tile[0 * XRT_TILE + tid]; ray.o.y = tile[1 * XRT_TILE + tid]; ray.o.z = tile[2 * XRT_TILE + tid];
-                        ray.d.x = tile[3 * XRT_TILE + tid]; ray.d.y = tile[4 * XRT_TILE + tid]; ray.d.z = tile[5 * XRT_TILE + tid];
-                        ray.wl = tile[6 * XRT_TILE + tid];
-                        id = tileid[tid];
-                    }
-                    // the next write to the tile happens behind the next scan's barrier
-                }
-                n_in = n_out;
+                spos += 2u * nb;
+                s_used += 2ull * nb;
+                const uint32_t freed = qhead;                     // these records are free again: compaction scratch
+                qhead = q_wrap(qhead + nb);
+                qcount -= nb;
+                plain_elements(be, false, nb, have, alive, ray, X, id, freed);
             }
         }
 
@@ -1310,7 +1355,7 @@ static void build_kscene(const xrt_scene_t* sc, char* ws, KScene* k)
 
 static size_t lds_bytes(int n_src_heads)
 {
-    size_t b = sizeof(double) * XRT_TILE_COMP * XRT_TILE + sizeof(uint32_t) * XRT_TILE;
+    size_t b = sizeof(double) * XRT_TILE_COMP * XRT_QCAP + sizeof(uint32_t) * XRT_QCAP;
     b += sizeof(uint32_t) * XRT_RING * (size_t)(n_src_heads + 1);
     b += sizeof(uint32_t) * (8 + 2 * (XRT_DEV_MAX_OPTICS + 2) + 8);
     return (b + 15) & ~(size_t)15;
@@ -1343,6 +1388,7 @@ static int launch_variant(const KScene& ks, const KArgs& a, int n_runs, size_t l
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, XRT_TILE, lds));
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 8) per_cu = 8;
+    if (const char* cap = getenv("XICSRT_MAX_WG_PER_CU")) { int c = atoi(cap); if (c >= 1 && c < per_cu) per_cu = c; }
     int grid = cus * per_cu;
     if (grid > n_runs) grid = n_runs;
     if (grid < 1) grid = 1;
