@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define XRT_ABI_VERSION 7
+#define XRT_ABI_VERSION 8
 
 #define XRT_MAX_OPTICS     16
 #define XRT_MAX_APERTURES  8
@@ -63,7 +63,8 @@ enum { XRT_WL_CONST = 0, XRT_WL_UNIFORM = 1, XRT_WL_NORMAL = 2, XRT_WL_VOIGT = 3
 /* Shape* classes (optics/_ShapePlane.py, _ShapeSphere.py, _ShapeCylinder.py, _ShapeTorus.py) */
 enum { XRT_SHAPE_PLANE = 0, XRT_SHAPE_SPHERE = 1, XRT_SHAPE_CYLINDER = 2, XRT_SHAPE_TORUS = 3 };
 /* Interact* classes (optics/_InteractNone.py, _InteractMirror.py, _InteractCrystal.py) */
-enum { XRT_INTERACT_NONE = 0, XRT_INTERACT_MIRROR = 1, XRT_INTERACT_CRYSTAL = 2 };
+enum { XRT_INTERACT_NONE = 0, XRT_INTERACT_MIRROR = 1, XRT_INTERACT_CRYSTAL = 2,
+       XRT_INTERACT_MOSAIC = 3   /* optics/_InteractMosaicCrystal.py:53-139 */ };
 /* rocking_type (optics/_InteractCrystal.py:138-149) */
 enum { XRT_ROCKING_STEP = 0, XRT_ROCKING_GAUSS = 1 };
 
@@ -158,6 +159,12 @@ typedef struct xrt_optic {
     double  rocking_half_fwhm;/* STEP: rocking_fwhm/2         (_InteractCrystal.py:141)    */
     double  rocking_2sigma2;  /* GAUSS: 2*sigma**2            (_InteractCrystal.py:146-149)*/
     double  half_pi;          /* np.pi/2                      (_InteractCrystal.py:112)    */
+    /* XRT_INTERACT_MOSAIC (optics/_InteractMosaicCrystal.py) */
+    int32_t mosaic_depth;     /* param['mosaic_depth']                                     */
+    int32_t mosaic_has_cutoff;/* param['mosaic_cutoff'] is not None                        */
+    double  mosaic_cutoff_angle; /* sqrt(-log(cutoff)*2*sigma**2)  (:67-72)                */
+    double  mosaic_A[4];      /* sqrt(s)[:,None]*v of svd(diag(sin(sigma_h)^2)), row-major:
+                               * factor of multivariate_normal (tools/xicsrt_spread.py:317-332) */
     double  pixel_size;       /* (_TraceObject.py:107)                                     */
     double  pixel_xoff;       /* (pixel_xsize-1)/2            (_TraceObject.py:269)        */
     double  pixel_yoff;

@@ -741,6 +741,92 @@ static void check_bounds(const xrt_optic_t* op, rays_t* r)
     }
 }
 
+/* optics/_InteractCrystal.py:96-115 angle_calc for one ray */
+static inline void angle_calc(const xrt_optic_t* op, const double* d, const double* nn, double wl, double* bragg, double* inc)
+{
+    double neg[3] = {-1.0 * nn[0], -1.0 * nn[1], -1.0 * nn[2]};
+    *bragg = asin(wl / op->two_d);
+    *inc = op->half_pi - acos(fabs(dot_e(d, neg)) / norm3(d));
+}
+
+/* optics/_InteractCrystal.py:136-196 reflection probability for one ray */
+static inline double rocking_p(const xrt_optic_t* op, double inc, double bragg)
+{
+    double p;
+    if (op->rocking_type == XRT_ROCKING_STEP) p = (fabs(inc - bragg) <= op->rocking_half_fwhm) ? 1.0 : 0.0;
+    else { double df = inc - bragg; p = exp(-(df * df) / op->rocking_2sigma2); }
+    return p * op->reflectivity;
+}
+
+/* optics/_InteractMosaicCrystal.py:53-139.  On entry r->mask = rays on the optic (after bounds),
+ * r->nrm = nominal normals.  Reflected rays get their new direction here; mask becomes the
+ * reflected set. */
+static void interact_mosaic(const xrt_optic_t* op, rays_t* r, mt_t* mt)
+{
+    const int64_t n = r->n;
+    if (op->mosaic_has_cutoff) {
+        for (int64_t i = 0; i < n; i++) {
+            if (!r->mask[i]) continue;
+            double bragg, inc;
+            angle_calc(op, &r->d[3 * i], &r->nrm[3 * i], r->wl[i], &bragg, &inc);
+            if (!(fabs(bragg - inc) < op->mosaic_cutoff_angle)) r->mask[i] = 0;
+        }
+    }
+    int64_t alive = 0;
+    for (int64_t i = 0; i < n; i++) alive += r->mask[i];
+    if (alive == 0) return;
+    uint8_t* refl = calloc((size_t)n, 1);
+    double* nm = malloc(sizeof(double) * 3 * (size_t)n);
+    const double* A = op->mosaic_A;
+    for (int ii = 0; ii < op->mosaic_depth; ii++) {
+        int64_t k = 0;
+        for (int64_t i = 0; i < n; i++) k += (r->mask[i] && !refl[i]);
+        if (k == 0) break;
+        /* mosaic_normals (:109-139): 2k standard normals row-major, then the frame about the nominal normal */
+        for (int64_t i = 0; i < n; i++) {
+            if (!(r->mask[i] && !refl[i])) continue;
+            double z0 = mt_gauss(mt), z1 = mt_gauss(mt);
+            double x = z0 * A[0] + z1 * A[2], y = z0 * A[1] + z1 * A[3];
+            x += 0.0; y += 0.0;
+            double o[3] = {x, y, 1.0};
+            double inv = 1.0 / norm3(o);
+            double l[3] = {o[0] * inv, o[1] * inv, o[2] * inv};
+            const double* nn = &r->nrm[3 * i];
+            const double ex[3] = {1.0, 0.0, 0.0}, ez[3] = {0.0, 0.0, 1.0};
+            double c1[3], c2[3], R0[3], R1[3];
+            cross3(nn, ex, c1);
+            cross3(nn, ez, c2);
+            for (int q = 0; q < 3; q++) R0[q] = c1[q] + c2[q];
+            double m0 = norm3(R0);
+            for (int q = 0; q < 3; q++) R0[q] /= m0;
+            cross3(nn, R0, R1);
+            double m1 = norm3(R1);
+            for (int q = 0; q < 3; q++) R1[q] /= m1;
+            for (int q = 0; q < 3; q++) nm[3 * i + q] = (l[0] * R0[q] + l[1] * R1[q]) + l[2] * nn[q];
+        }
+        /* angle_check with the crystallite normals, then reflect the accepted rays */
+        for (int64_t i = 0; i < n; i++) {
+            if (!(r->mask[i] && !refl[i])) continue;
+            int ok = 1;
+            if (op->flags & XRT_F_CHECK_BRAGG) {
+                double bragg, inc;
+                angle_calc(op, &r->d[3 * i], &nm[3 * i], r->wl[i], &bragg, &inc);
+                double p = rocking_p(op, inc, bragg);
+                double test = 0.0 + (1.0 - 0.0) * mt_double(mt);
+                ok = (p >= test);
+            }
+            if (ok) {
+                double* d = &r->d[3 * i];
+                double dt = dot_e(d, &nm[3 * i]);
+                for (int q = 0; q < 3; q++) d[q] = d[q] - 2.0 * (dt * nm[3 * i + q]);
+                refl[i] = 1;
+            }
+        }
+    }
+    for (int64_t i = 0; i < n; i++) r->mask[i] = r->mask[i] && refl[i];
+    free(refl); free(nm);
+}
+
 /* optics/_InteractCrystal.py:96-196: Bragg test, draws in original ray order */
 static void angle_check(const xrt_optic_t* op, rays_t* r, mt_t* mt)
 {
@@ -790,6 +876,8 @@ static void trace_optic(const xrt_optic_t* op, rays_t* r, mt_t* mt)
     check_bounds(op, r);
     if (op->interact == XRT_INTERACT_CRYSTAL && (op->flags & XRT_F_CHECK_BRAGG))
         angle_check(op, r, mt);
+    if (op->interact == XRT_INTERACT_MOSAIC)
+        interact_mosaic(op, r, mt);
     for (int64_t i = 0; i < r->n; i++) {
         /* InteractObject.interact / InteractMirror.reflect_vectors (_InteractMirror.py:29-42):
          * O[:] = xloc for every ray (NaN where there was no intersection) */
@@ -802,7 +890,7 @@ static void trace_optic(const xrt_optic_t* op, rays_t* r, mt_t* mt)
             continue;
         }
         for (int k = 0; k < 3; k++) o[k] = x[k];
-        if (op->interact != XRT_INTERACT_NONE) {
+        if (op->interact != XRT_INTERACT_NONE && op->interact != XRT_INTERACT_MOSAIC) {
             double dt = dot_e(d, nn);
             for (int k = 0; k < 3; k++) d[k] = d[k] - 2.0 * (dt * nn[k]);
         }

@@ -270,6 +270,17 @@ def build_cases():
     cfg2['sources']['source']['intensity'] = 50000
     add('Q_four_counts', 'counts', cfg2)
 
+    # --- mosaic crystals (multi-layer model: per pass 2k normals then k uniforms) ----------
+    mos = dict(_BRAGG, rocking_fwhm=2.0e-3, mosaic_spread=float(np.radians(0.4)), mosaic_depth=6)
+    c = _crystal('XicsrtOpticPlanarMosaicCrystal', **mos)
+    add('M_planar_mosaic_trace', 'trace', cfg_three(2000, c, history=True, seed=91))
+    add('M_planar_mosaic_counts', 'counts', cfg_three(30000, c, seed=91, runs=2, iters=2))
+    c = _crystal('XicsrtOpticSphericalMosaicCrystal', radius=1.0, mosaic_cutoff=1e-3, **mos)
+    add('M_spherical_mosaic_cutoff_trace', 'trace', cfg_three(2000, c, history=True, seed=92))
+    add('M_spherical_mosaic_cutoff_1e5', 'counts', cfg_three(100000, c, seed=92))
+    c = _crystal('XicsrtOpticSphericalMosaicCrystal', radius=1.0, check_bragg=False, **mos)
+    add('M_spherical_mosaic_nobragg_trace', 'trace', cfg_three(500, c, history=True, seed=93))
+
     # --- full results dictionary with histories (found / shuffled lost sample) ---
     cfg = cfg_three(3000, dict(sph, rocking_fwhm=2e-3), seed=81, runs=2, iters=2, history=True)
     cfg['general']['history_max_lost'] = 200

@@ -87,6 +87,9 @@ struct KOptic {
     double  torus_k[5];
     int32_t torus_root, pad0;
     double  two_d, reflectivity, half_fwhm, two_sigma2, half_pi;
+    double  mosaic_cutoff_angle;
+    double  mosaic_A[4];
+    int32_t mosaic_depth, mosaic_has_cutoff;
     double  pixel_size, pixel_xoff, pixel_yoff;
     int32_t pixel_nx, pixel_ny;
     int64_t image_offset;
@@ -557,6 +560,16 @@ __device__ __forceinline__ bool check_bounds(const KOptic& op, const V3& X)
 }
 
 // InteractCrystal.angle_calc + rocking_curve_filter (optics/_InteractCrystal.py:96-196)
+// angle_calc (optics/_InteractCrystal.py:96-115): |bragg - incident| for the mosaic cutoff
+__device__ __forceinline__ double bragg_offset(const KOptic& op, const Ray& ray, const V3& nrm)
+{
+    double bragg = asin(ray.wl / op.two_d);
+    V3 neg; neg.x = -1.0 * nrm.x; neg.y = -1.0 * nrm.y; neg.z = -1.0 * nrm.z;
+    double dt = fabs(dot_e(ray.d, neg));
+    double inc = op.half_pi - acos(dt / norm3(ray.d));
+    return fabs(bragg - inc);
+}
+
 __device__ __forceinline__ bool bragg_accept(const KOptic& op, const Ray& ray, const V3& nrm, double test,
                                              bool have_bragg, double bragg_shared)
 {
@@ -1208,8 +1221,10 @@ extern "C" int xrt_scene_check(const xrt_scene_t* sc)
             return fail(-3, "%s", "optic shape is not implemented on the device path");
         if (o.shape == XRT_SHAPE_TORUS && (o.torus_root < 0 || o.torus_root > 3))
             return fail(-2, "%s", "torus root index out of range");
-        if (o.interact < XRT_INTERACT_NONE || o.interact > XRT_INTERACT_CRYSTAL)
+        if (o.interact < XRT_INTERACT_NONE || o.interact > XRT_INTERACT_MOSAIC)
             return fail(-3, "%s", "optic interaction is not implemented on the device path");
+        if (o.interact == XRT_INTERACT_MOSAIC && (o.mosaic_depth < 0 || o.mosaic_depth > 1000))
+            return fail(-2, "%s", "mosaic_depth out of range");
         if (o.flags & XRT_F_TRACE_LOCAL)
             return fail(-3, "%s", "trace_local is not implemented on the device path");
         if (o.n_apertures < 0 || o.n_apertures > XRT_MAX_APERTURES) return fail(-2, "%s", "bad aperture count");
@@ -1252,8 +1267,10 @@ static bool needs_staged(const xrt_scene_t* sc)
     if (s.spatial_dist == XRT_SPATIAL_GAUSSIAN || s.angular_dist == XRT_ANG_ISOTROPIC_XY || s.wavelength_dist == XRT_WL_NORMAL)
         return true;
     int n_bragg = 0;
-    for (int e = 0; e < sc->n_optics; e++)
+    for (int e = 0; e < sc->n_optics; e++) {
+        if (sc->optics[e].interact == XRT_INTERACT_MOSAIC) return true;     // whole-array passes per layer
         if (sc->optics[e].interact == XRT_INTERACT_CRYSTAL && (sc->optics[e].flags & XRT_F_CHECK_BRAGG)) n_bragg++;
+    }
     return n_bragg > 1;
 }
 #define XRT_ST_SLOTS 128
@@ -1346,6 +1363,9 @@ static void build_kscene(const xrt_scene_t* sc, char* ws, KScene* k)
         for (int i = 0; i < 5; i++) q.torus_k[i] = o.torus_k[i];
         q.two_d = o.two_d; q.reflectivity = o.reflectivity; q.half_fwhm = o.rocking_half_fwhm;
         q.two_sigma2 = o.rocking_2sigma2; q.half_pi = o.half_pi;
+        q.mosaic_depth = o.mosaic_depth; q.mosaic_has_cutoff = o.mosaic_has_cutoff;
+        q.mosaic_cutoff_angle = o.mosaic_cutoff_angle;
+        for (int i = 0; i < 4; i++) q.mosaic_A[i] = o.mosaic_A[i];
         q.pixel_size = o.pixel_size; q.pixel_xoff = o.pixel_xoff; q.pixel_yoff = o.pixel_yoff;
         q.pixel_nx = o.pixel_nx; q.pixel_ny = o.pixel_ny; q.image_offset = o.image_offset;
         q.n_apertures = o.n_apertures;

@@ -195,6 +195,23 @@ class InteractCrystal(InteractMirror):
         self.param['rocking_type'] = str.lower(self.param['rocking_type'])
 
 
+class InteractMosaicCrystal(InteractCrystal):
+    """Multi-layer mosaic (HOPG-like) crystal (xicsrt/optics/_InteractMosaicCrystal.py:18-139)."""
+    interact_kind = 'mosaic'
+
+    def default_config(self):
+        """
+        mosaic_spread : fwhm of the crystallite-normal distribution [rad]
+        mosaic_depth  : number of crystallite layers modelled
+        mosaic_cutoff : probability cutoff to skip rays far from the Bragg angle (None = off)
+        """
+        config = super().default_config()
+        config['mosaic_spread'] = 0.0
+        config['mosaic_depth'] = 15
+        config['mosaic_cutoff'] = None
+        return config
+
+
 # ---- the named element classes ------------------------------------------------
 
 _ELEMENTS = (
@@ -207,6 +224,8 @@ _ELEMENTS = (
     ('XicsrtOpticCylindricalMirror', InteractMirror, ShapeCylinder),
     ('XicsrtOpticCylindricalCrystal', InteractCrystal, ShapeCylinder),
     ('XicsrtOpticToroidalCrystal', InteractCrystal, ShapeTorus),
+    ('XicsrtOpticPlanarMosaicCrystal', InteractMosaicCrystal, ShapePlane),
+    ('XicsrtOpticSphericalMosaicCrystal', InteractMosaicCrystal, ShapeSphere),
 )
 
 BUILTIN = {}
@@ -222,6 +241,5 @@ del _name, _interact, _shape, _cls
 NOT_IMPLEMENTED = (
     'XicsrtOpticMeshCrystal', 'XicsrtOpticMeshMirror', 'XicsrtOpticMeshMosaicCrystal',
     'XicsrtOpticMeshSphericalCrystal', 'XicsrtOpticMeshCylindricalCrystal',
-    'XicsrtOpticMeshToroidalCrystal', 'XicsrtOpticPlanarMosaicCrystal',
-    'XicsrtOpticSphericalMosaicCrystal',
+    'XicsrtOpticMeshToroidalCrystal',
 )

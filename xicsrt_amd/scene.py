@@ -20,7 +20,7 @@ import ctypes as C
 
 import numpy as np
 
-XRT_ABI_VERSION = 7
+XRT_ABI_VERSION = 8
 XRT_MAX_OPTICS = 16
 XRT_MAX_APERTURES = 8
 XRT_HIST_COMPONENTS = 8
@@ -30,7 +30,7 @@ SPATIAL = {'uniform': 0, 'gaussian': 1}
 ANGULAR = {'isotropic': 0, 'isotropic_xy': 1, 'flat': 2, 'flat_xy': 3}
 WL_CONST, WL_UNIFORM, WL_NORMAL, WL_VOIGT = 0, 1, 2, 3
 SHAPE = {'plane': 0, 'sphere': 1, 'cylinder': 2, 'torus': 3}
-INTERACT = {'none': 0, 'mirror': 1, 'crystal': 2}
+INTERACT = {'none': 0, 'mirror': 1, 'crystal': 2, 'mosaic': 3}
 ROCKING_STEP, ROCKING_GAUSS = 0, 1
 AP_SHAPE = {'none': 0, 'circle': 1, 'square': 2, 'rectangle': 3, 'ellipse': 4, 'triangle': 5}
 AP_LOGIC = {'and': 0, 'not': 1, 'or': 2, 'nand': 3, 'nor': 4, 'xor': 5, 'xnor': 6}
@@ -73,6 +73,8 @@ class Optic(C.Structure):
                 ('two_d', C.c_double), ('reflectivity', C.c_double),
                 ('rocking_half_fwhm', C.c_double), ('rocking_2sigma2', C.c_double),
                 ('half_pi', C.c_double),
+                ('mosaic_depth', C.c_int32), ('mosaic_has_cutoff', C.c_int32),
+                ('mosaic_cutoff_angle', C.c_double), ('mosaic_A', C.c_double * 4),
                 ('pixel_size', C.c_double), ('pixel_xoff', C.c_double), ('pixel_yoff', C.c_double),
                 ('pixel_nx', C.c_int32), ('pixel_ny', C.c_int32),
                 ('image_offset', C.c_int64),
@@ -382,7 +384,25 @@ def flatten_optic(obj, out, image_offset):
     out.two_d = out.rocking_half_fwhm = out.rocking_2sigma2 = 0.0
     out.reflectivity = 1.0
     out.half_pi = float(np.pi / 2)
-    if obj.interact_kind == 'crystal':
+    out.mosaic_depth = 0
+    out.mosaic_has_cutoff = 0
+    out.mosaic_cutoff_angle = 0.0
+    _vec(out.mosaic_A, np.zeros(4))
+    if obj.interact_kind == 'mosaic':
+        out.mosaic_depth = int(p['mosaic_depth'])
+        if p['mosaic_cutoff'] is not None:
+            out.mosaic_has_cutoff = 1
+            angle_sigma = p['mosaic_spread'] / (2 * np.sqrt(2 * np.log(2)))
+            out.mosaic_cutoff_angle = float(np.sqrt(-1 * np.log(p['mosaic_cutoff']) * 2 * angle_sigma ** 2))
+        # vector_dist_flat_gaussian(mosaic_spread / 2, n) (tools/xicsrt_spread.py:297-339)
+        theta = _parse_spread_single(p['mosaic_spread'] / 2.0)
+        sigma = theta[0] / (np.sqrt(2 * np.log(2)))
+        xsigma = np.sin(sigma)
+        ysigma = np.sin(sigma)
+        cov = np.array([[xsigma ** 2, 0], [0, ysigma ** 2]])
+        (u, sv, v) = np.linalg.svd(cov.astype(np.double))
+        _vec(out.mosaic_A, np.sqrt(sv)[:, None] * v)
+    if obj.interact_kind in ('crystal', 'mosaic'):
         # `check_bragg is False` is the reference's test (_InteractCrystal.py:120)
         if p['check_bragg'] is not False:
             flags |= F_CHECK_BRAGG
