@@ -145,22 +145,29 @@ def test_library_exports_every_declared_symbol():
     assert L.xrt_sizeof_scene() == C.sizeof(xscene.Scene)
 
 
-@pytest.mark.parametrize('name,pattern', [
-    ('P_local_trace', b'trace_local')])
-def test_unsupported_scenes_fail_loudly(name, pattern):
-    """No CPU fallback: features outside the device path are refused by xrt_scene_check."""
-    cfg, gold = helpers.load_golden(name)
-    config, elements, flat = helpers.build(cfg)
+def test_unsupported_scenes_fail_loudly():
+    """No CPU fallback: features outside the device path are refused (class lookup or xrt_scene_check)."""
     L = capi.lib()
+    cfg, gold = helpers.load_golden('M_planar_mosaic_trace')
+    cfg['optics']['crystal']['trace_local'] = True
+    config, elements, flat = helpers.build(cfg)
     assert L.xrt_scene_check(flat.byref()) != 0
-    assert pattern in L.xrt_last_error()
+    assert b'trace_local' in L.xrt_last_error()
+    cfg, gold = helpers.load_golden('E_mesh_flat_trace')
+    with pytest.raises(NotImplementedError):
+        helpers.build(cfg)
+    cfg, gold = helpers.load_golden('F_plasma_trace')
+    cfg['sources']['source'].update(spread=None, spread_radius=0.05)
+    with pytest.raises(NotImplementedError):
+        helpers.build(cfg)
 
 
 def test_supported_scenes_validate():
     L = capi.lib()
     for name in ('A_example00_trace', 'B_mirror_trace', 'C_sphere_trace', 'D_CylindricalCrystal_trace',
                  'P_aperture2_trace', 'W_voigt_trace', 'S_focused_trace', 'G_flat_xy_trace',
-                 'W_normal_trace', 'S_gaussian_spatial_trace', 'G_isotropic_xy_trace', 'Q_four_trace'):
+                 'W_normal_trace', 'S_gaussian_spatial_trace', 'G_isotropic_xy_trace', 'Q_four_trace',
+                 'P_local_trace', 'M_spherical_mosaic_cutoff_trace', 'F_plasma_trace', 'D_ToroidalCrystal_trace'):
         cfg, gold = helpers.load_golden(name)
         config, elements, flat = helpers.build(cfg)
         assert L.xrt_scene_check(flat.byref()) == 0, (name, L.xrt_last_error())

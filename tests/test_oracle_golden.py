@@ -9,7 +9,7 @@ import pytest
 import helpers
 
 # golden cases whose features the oracle / device path implement so far
-SKIP_PREFIX = ('E_mesh', 'P_local', 'H_history')
+SKIP_PREFIX = ('E_mesh', 'H_history')
 
 
 def _cases(kind):

@@ -203,6 +203,16 @@ __device__ __forceinline__ V3 to_local(const double* R, const V3& v)
     return o;
 }
 
+// GeometryObject.vector_to_external: einsum('ij,ki->kj') (xicsrt/objects/_GeometryObject.py:143-155)
+__device__ __forceinline__ V3 to_external(const double* R, const V3& v)
+{
+    V3 o;
+    o.x = (R[0] * v.x + R[3] * v.y) + R[6] * v.z;
+    o.y = (R[1] * v.x + R[4] * v.y) + R[7] * v.z;
+    o.z = (R[2] * v.x + R[5] * v.y) + R[8] * v.z;
+    return o;
+}
+
 // np.interp (numpy/core/src/multiarray/compiled_base.c arr_interp)
 __device__ double np_interp(double x, const double* xp, const double* fp, int n)
 {
@@ -415,9 +425,15 @@ __device__ __forceinline__ bool intersect_point(const KOptic& op, const Ray& ray
     double t;
     if (op.shape == XRT_SHAPE_PLANE) {
         // optics/_ShapePlane.py:32-52 (np.dot -> OpenBLAS dgemv fused order)
-        V3 za = ld3(op.R + 6);
-        V3 v = sub3(ld3(op.origin), ray.o);
-        t = dot_blas(v, za) / dot_blas(ray.d, za);
+        if (FULL && (op.flags & XRT_F_TRACE_LOCAL)) {
+            V3 ez; ez.x = 0.0; ez.y = 0.0; ez.z = 1.0;
+            V3 v; v.x = 0.0 - ray.o.x; v.y = 0.0 - ray.o.y; v.z = 0.0 - ray.o.z;
+            t = dot_blas(v, ez) / dot_blas(ray.d, ez);
+        } else {
+            V3 za = ld3(op.R + 6);
+            V3 v = sub3(ld3(op.origin), ray.o);
+            t = dot_blas(v, za) / dot_blas(ray.d, za);
+        }
         if (!(t >= 0.0)) return false;
     } else if (!FULL || op.shape == XRT_SHAPE_SPHERE) {
         // optics/_ShapeSphere.py:52-100
@@ -532,7 +548,7 @@ __device__ bool aperture_shape(const xrt_aperture_t& a, double x, double y)
 template <bool FULL>
 __device__ __forceinline__ bool check_bounds(const KOptic& op, const V3& X)
 {
-    V3 loc = to_local(op.R, sub3(X, ld3(op.origin)));
+    V3 loc = (FULL && (op.flags & XRT_F_TRACE_LOCAL)) ? X : to_local(op.R, sub3(X, ld3(op.origin)));
     bool m = true;
     if (op.flags & XRT_F_CHECK_SIZE) {
         if ((op.flags & XRT_F_HAS_XSIZE) && !(fabs(loc.x) < op.half_size[0])) m = false;
@@ -1225,8 +1241,8 @@ extern "C" int xrt_scene_check(const xrt_scene_t* sc)
             return fail(-3, "%s", "optic interaction is not implemented on the device path");
         if (o.interact == XRT_INTERACT_MOSAIC && (o.mosaic_depth < 0 || o.mosaic_depth > 1000))
             return fail(-2, "%s", "mosaic_depth out of range");
-        if (o.flags & XRT_F_TRACE_LOCAL)
-            return fail(-3, "%s", "trace_local is not implemented on the device path");
+        if (o.interact == XRT_INTERACT_MOSAIC && (o.flags & XRT_F_TRACE_LOCAL))
+            return fail(-3, "%s", "mosaic crystals with trace_local are not implemented on the device path");
         if (o.n_apertures < 0 || o.n_apertures > XRT_MAX_APERTURES) return fail(-2, "%s", "bad aperture count");
         if ((o.flags & XRT_F_IMAGE) && (o.pixel_nx <= 0 || o.pixel_ny <= 0 || o.image_offset < 0 ||
                                         o.image_offset + (int64_t)o.pixel_nx * o.pixel_ny > sc->image_bins))
@@ -1269,6 +1285,7 @@ static bool needs_staged(const xrt_scene_t* sc)
     int n_bragg = 0;
     for (int e = 0; e < sc->n_optics; e++) {
         if (sc->optics[e].interact == XRT_INTERACT_MOSAIC) return true;     // whole-array passes per layer
+        if (sc->optics[e].flags & XRT_F_TRACE_LOCAL) return true;
         if (sc->optics[e].interact == XRT_INTERACT_CRYSTAL && (sc->optics[e].flags & XRT_F_CHECK_BRAGG)) n_bragg++;
     }
     return n_bragg > 1;
