@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define XRT_ABI_VERSION 8
+#define XRT_ABI_VERSION 9
 
 #define XRT_MAX_OPTICS     16
 #define XRT_MAX_APERTURES  8
@@ -61,7 +61,8 @@ enum { XRT_ANG_ISOTROPIC = 0, XRT_ANG_ISOTROPIC_XY = 1, XRT_ANG_FLAT = 2, XRT_AN
 enum { XRT_WL_CONST = 0, XRT_WL_UNIFORM = 1, XRT_WL_NORMAL = 2, XRT_WL_VOIGT = 3 };
 
 /* Shape* classes (optics/_ShapePlane.py, _ShapeSphere.py, _ShapeCylinder.py, _ShapeTorus.py) */
-enum { XRT_SHAPE_PLANE = 0, XRT_SHAPE_SPHERE = 1, XRT_SHAPE_CYLINDER = 2, XRT_SHAPE_TORUS = 3 };
+enum { XRT_SHAPE_PLANE = 0, XRT_SHAPE_SPHERE = 1, XRT_SHAPE_CYLINDER = 2, XRT_SHAPE_TORUS = 3,
+       XRT_SHAPE_MESH = 4   /* optics/_ShapeMesh.py */ };
 /* Interact* classes (optics/_InteractNone.py, _InteractMirror.py, _InteractCrystal.py) */
 enum { XRT_INTERACT_NONE = 0, XRT_INTERACT_MIRROR = 1, XRT_INTERACT_CRYSTAL = 2,
        XRT_INTERACT_MOSAIC = 3   /* optics/_InteractMosaicCrystal.py:53-139 */ };
@@ -137,6 +138,36 @@ typedef struct xrt_source {
     int32_t pad_plasma;
 } xrt_source_t;
 
+/* A triangulated-mesh surface (optics/_ShapeMesh.py:198-261 _mesh_precalc output), all HOST
+ * pointers, copied to the device per call.  Built by the host with SciPy exactly where the
+ * reference uses it (Delaunay, CloughTocher2DInterpolator gradients). */
+typedef struct xrt_mesh {
+    int32_t n_points, n_faces;          /* fine mesh                                           */
+    int32_t n_coarse_faces;             /* > 0: pre-selection mesh (mesh_refine), 0: search the fine mesh */
+    int32_t interpolate;                /* mesh_interpolate                                    */
+    int32_t n_simplices, pad;           /* x-y Delaunay used by the interpolators              */
+    const double*  points;              /* [n_points][3]                                       */
+    const double*  p0;                  /* [n_faces][3] vertices of every face                 */
+    const double*  p1;
+    const double*  p2;
+    const double*  edge1;               /* [n_faces][3] p1-p0, p2-p0 (Moller-Trumbore, :289-348) */
+    const double*  edge2;
+    const double*  faces_normal;        /* [n_faces][3]  (:240-241)                            */
+    const double*  faces_area;          /* [n_faces] |(p0-p1)x(p0-p2)|  (:405)                 */
+    const int32_t* p_faces_idx;         /* [8][n_points] faces around each point (:446-462)    */
+    const uint8_t* p_faces_mask;        /* [8][n_points]                                       */
+    const double*  c_p0;                /* [n_coarse_faces][3] coarse mesh faces               */
+    const double*  c_edge1;
+    const double*  c_edge2;
+    const int32_t* ct_simplices;        /* [n_simplices][3]                                    */
+    const int32_t* ct_neighbors;        /* [n_simplices][3]                                    */
+    const double*  ct_transform;        /* [n_simplices][3][2] barycentric transforms          */
+    const double*  ct_points;           /* [n_points][2]                                       */
+    const double*  ct_values;           /* [4][n_points]  z, normal_x, normal_y, normal_z      */
+    const double*  ct_grad;             /* [4][n_points][2] vertex gradients                   */
+    const int32_t* ct_vertex_simplex;   /* [n_points] a simplex containing the vertex          */
+} xrt_mesh_t;
+
 typedef struct xrt_optic {
     int32_t shape;            /* XRT_SHAPE_*    */
     int32_t interact;         /* XRT_INTERACT_* */
@@ -171,6 +202,7 @@ typedef struct xrt_optic {
     int32_t pixel_nx;
     int32_t pixel_ny;
     int64_t image_offset;     /* first bin of this optic's image in images[] (row-major [nx][ny]) */
+    const xrt_mesh_t* mesh;   /* XRT_SHAPE_MESH only (HOST pointer)                        */
     xrt_aperture_t apertures[XRT_MAX_APERTURES];
 } xrt_optic_t;
 

@@ -672,6 +672,201 @@ static void intersect_torus(const xrt_optic_t* op, rays_t* r)
     }
 }
 
+/* ---- mesh optics (optics/_ShapeMesh.py) ---------------------------------------------- */
+
+/* Moller-Trumbore over every face, later faces overwrite earlier hits (:289-348).
+ * np.einsum('i,ji->j', ..., optimize=True) is a BLAS matrix-vector product (fused order),
+ * the 'ij,ij->i' forms are numpy's own (p0 + p2) + p1. */
+static int mesh_intersect_1(const double* P0, const double* E1, const double* E2, int nf,
+                            const double* O, const double* D, double* X, int* hit_face)
+{
+    const double epsilon = 1e-15;
+    int hit = 0;
+    for (int ii = 0; ii < nf; ii++) {
+        const double* p0 = P0 + 3 * ii; const double* e1 = E1 + 3 * ii; const double* e2 = E2 + 3 * ii;
+        double h[3], s[3], q[3];
+        cross3(D, e2, h);
+        double f = dot_blas(h, e1);
+        if ((f > -epsilon) && (f < epsilon)) continue;
+        f = 1.0 / f;
+        for (int k = 0; k < 3; k++) s[k] = O[k] - p0[k];
+        double u = f * dot_e(s, h);
+        if ((u < 0.0) || (u > 1.0)) continue;
+        cross3(s, e1, q);
+        double v = f * dot_e(D, q);
+        if ((v < 0.0) || (u + v > 1.0)) continue;
+        double t = f * dot_blas(q, e2);
+        hit = 1;
+        *hit_face = ii;
+        for (int k = 0; k < 3; k++) X[k] = O[k] + t * D[k];
+    }
+    return hit;
+}
+
+/* cKDTree(points).query(x)[1]: index of the nearest point (:464-475) */
+static int mesh_nearest(const xrt_mesh_t* M, const double* x)
+{
+    int best = 0;
+    double bd = INFINITY;
+    for (int i = 0; i < M->n_points; i++) {
+        const double* p = M->points + 3 * i;
+        double dx = x[0] - p[0], dy = x[1] - p[1], dz = x[2] - p[2];
+        double d = (dx * dx + dy * dy) + dz * dz;
+        if (d < bd) { bd = d; best = i; }
+    }
+    return best;
+}
+
+/* the <= 8 faces around the nearest point: plane hit + area-sum test, first passing (:350-426) */
+static int mesh_intersect_2(const xrt_mesh_t* M, int idx, const double* O, const double* D, double* X, int* hit_face)
+{
+    for (int k = 0; k < 8; k++) {
+        const int f = M->p_faces_idx[k * M->n_points + idx];
+        const int valid = M->p_faces_mask[k * M->n_points + idx];
+        const double* p0 = M->p0 + 3 * f; const double* p1 = M->p1 + 3 * f; const double* p2 = M->p2 + 3 * f;
+        const double* n = M->faces_normal + 3 * f;
+        double t0[3] = {p0[0] - O[0], p0[1] - O[1], p0[2] - O[2]};
+        double t1 = dot_e(t0, n), t2 = dot_e(D, n);
+        double dist = t1 / t2;
+        double I[3], a[3], b[3], c[3], bc[3], ca[3], ab[3];
+        for (int q = 0; q < 3; q++) I[q] = D[q] * dist + O[q];
+        for (int q = 0; q < 3; q++) { a[q] = I[q] - p0[q]; b[q] = I[q] - p1[q]; c[q] = I[q] - p2[q]; }
+        cross3(b, c, bc); cross3(c, a, ca); cross3(a, b, ab);
+        double diff = ((norm3(bc) + norm3(ca)) + norm3(ab)) - M->faces_area[f];
+        if ((diff < 1e-10) && (dist >= 0) && valid) {
+            for (int q = 0; q < 3; q++) X[q] = I[q];
+            *hit_face = f;
+            return 1;
+        }
+    }
+    return 0;
+}
+
+/* SciPy CloughTocher2DInterpolator (third party, scipy 1.15.3 interpnd: barycentric walk +
+ * _clough_tocher_2d_single), restated; verified against SciPy in tests/tools/ct_check.py */
+static void ct_bary(const double* T, const double* x, double* c)
+{
+    c[2] = 1.0;
+    for (int i = 0; i < 2; i++) {
+        c[i] = 0.0;
+        for (int j = 0; j < 2; j++) c[i] += T[2 * i + j] * (x[j] - T[4 + j]);
+        c[2] -= c[i];
+    }
+}
+
+static int ct_find_simplex(const xrt_mesh_t* M, const double* x, int start, double* c)
+{
+    const double eps = 100 * 2.220446049250313e-16;
+    int s = start;
+    if (x[0] != x[0] || x[1] != x[1]) return -1;
+    for (int iter = 0; iter < M->n_simplices + 8; iter++) {
+        ct_bary(M->ct_transform + 6 * s, x, c);
+        int worst = -1;
+        double wv = -eps;
+        for (int k = 0; k < 3; k++) if (c[k] < wv) { wv = c[k]; worst = k; }
+        if (worst < 0) return s;
+        int nb = M->ct_neighbors[3 * s + worst];
+        if (nb < 0) break;
+        s = nb;
+    }
+    for (s = 0; s < M->n_simplices; s++) {          /* exhaustive fallback */
+        ct_bary(M->ct_transform + 6 * s, x, c);
+        if (c[0] >= -eps && c[1] >= -eps && c[2] >= -eps) return s;
+    }
+    return -1;
+}
+
+static double ct_eval(const xrt_mesh_t* M, int isimplex, const double* b, int which)
+{
+    const int* v = M->ct_simplices + 3 * isimplex;
+    const double* pts = M->ct_points;
+    const double* val = M->ct_values + (size_t)which * M->n_points;
+    const double* grd = M->ct_grad + (size_t)which * M->n_points * 2;
+    double e12x = pts[2 * v[1]] - pts[2 * v[0]], e12y = pts[2 * v[1] + 1] - pts[2 * v[0] + 1];
+    double e23x = pts[2 * v[2]] - pts[2 * v[1]], e23y = pts[2 * v[2] + 1] - pts[2 * v[1] + 1];
+    double e31x = pts[2 * v[0]] - pts[2 * v[2]], e31y = pts[2 * v[0] + 1] - pts[2 * v[2] + 1];
+    double f1 = val[v[0]], f2 = val[v[1]], f3 = val[v[2]];
+    const double* d1 = grd + 2 * v[0]; const double* d2 = grd + 2 * v[1]; const double* d3 = grd + 2 * v[2];
+    double df12 = +(d1[0] * e12x + d1[1] * e12y);
+    double df21 = -(d2[0] * e12x + d2[1] * e12y);
+    double df23 = +(d2[0] * e23x + d2[1] * e23y);
+    double df32 = -(d3[0] * e23x + d3[1] * e23y);
+    double df31 = +(d3[0] * e31x + d3[1] * e31y);
+    double df13 = -(d1[0] * e31x + d1[1] * e31y);
+    double c3000 = f1, c2100 = (df12 + 3 * c3000) / 3, c2010 = (df13 + 3 * c3000) / 3;
+    double c0300 = f2, c1200 = (df21 + 3 * c0300) / 3, c0210 = (df23 + 3 * c0300) / 3;
+    double c0030 = f3, c1020 = (df31 + 3 * c0030) / 3, c0120 = (df32 + 3 * c0030) / 3;
+    double c2001 = (c2100 + c2010 + c3000) / 3;
+    double c0201 = (c1200 + c0300 + c0210) / 3;
+    double c0021 = (c1020 + c0120 + c0030) / 3;
+    double g[3];
+    for (int k = 0; k < 3; k++) {
+        int itri = M->ct_neighbors[3 * isimplex + k];
+        if (itri == -1) { g[k] = -1. / 2; continue; }
+        const int* w = M->ct_simplices + 3 * itri;
+        double y[2], c[3];
+        y[0] = (pts[2 * w[0]] + pts[2 * w[1]] + pts[2 * w[2]]) / 3;
+        y[1] = (pts[2 * w[0] + 1] + pts[2 * w[1] + 1] + pts[2 * w[2] + 1]) / 3;
+        ct_bary(M->ct_transform + 6 * isimplex, y, c);
+        if (k == 0)      g[k] = (2 * c[2] + c[1] - 1) / (2 - 3 * c[2] - 3 * c[1]);
+        else if (k == 1) g[k] = (2 * c[0] + c[2] - 1) / (2 - 3 * c[0] - 3 * c[2]);
+        else             g[k] = (2 * c[1] + c[0] - 1) / (2 - 3 * c[1] - 3 * c[0]);
+    }
+    double c0111 = (g[0] * (-c0300 + 3 * c0210 - 3 * c0120 + c0030) + (-c0300 + 2 * c0210 - c0120 + c0021 + c0201)) / 2;
+    double c1011 = (g[1] * (-c0030 + 3 * c1020 - 3 * c2010 + c3000) + (-c0030 + 2 * c1020 - c2010 + c2001 + c0021)) / 2;
+    double c1101 = (g[2] * (-c3000 + 3 * c2100 - 3 * c1200 + c0300) + (-c3000 + 2 * c2100 - c1200 + c2001 + c0201)) / 2;
+    double c1002 = (c1101 + c1011 + c2001) / 3;
+    double c0102 = (c1101 + c0111 + c0201) / 3;
+    double c0012 = (c1011 + c0111 + c0021) / 3;
+    double c0003 = (c1002 + c0102 + c0012) / 3;
+    double minval = b[0];
+    for (int k = 0; k < 3; k++) if (b[k] < minval) minval = b[k];
+    double b1 = b[0] - minval, b2 = b[1] - minval, b3 = b[2] - minval, b4 = 3 * minval;
+    return (pow(b1, 3) * c3000 + 3 * pow(b1, 2) * b2 * c2100 + 3 * pow(b1, 2) * b3 * c2010 + 3 * pow(b1, 2) * b4 * c2001 +
+            3 * b1 * pow(b2, 2) * c1200 + 6 * b1 * b2 * b4 * c1101 + 3 * b1 * pow(b3, 2) * c1020 + 6 * b1 * b3 * b4 * c1011 +
+            3 * b1 * pow(b4, 2) * c1002 + pow(b2, 3) * c0300 + 3 * pow(b2, 2) * b3 * c0210 + 3 * pow(b2, 2) * b4 * c0201 +
+            3 * b2 * pow(b3, 2) * c0120 + 6 * b2 * b3 * b4 * c0111 + 3 * b2 * pow(b4, 2) * c0102 + pow(b3, 3) * c0030 +
+            3 * pow(b3, 2) * b4 * c0021 + 3 * b3 * pow(b4, 2) * c0012 + pow(b4, 3) * c0003);
+}
+
+/* ShapeMesh.intersect (:135-170) for rays already in the optic's frame */
+static void intersect_mesh(const xrt_optic_t* op, rays_t* r)
+{
+    const xrt_mesh_t* M = op->mesh;
+    for (int64_t i = 0; i < r->n; i++) {
+        if (!r->mask[i]) continue;
+        const double* o = &r->o[3 * i];
+        const double* d = &r->d[3 * i];
+        double* x = &r->x[3 * i];
+        int face = 0, idx = -1;
+        if (M->n_coarse_faces > 0) {
+            double xc[3];
+            if (!mesh_intersect_1(M->c_p0, M->c_edge1, M->c_edge2, M->n_coarse_faces, o, d, xc, &face)) { r->mask[i] = 0; continue; }
+            idx = mesh_nearest(M, xc);
+            if (!mesh_intersect_2(M, idx, o, d, x, &face)) { r->mask[i] = 0; continue; }
+        } else {
+            if (!mesh_intersect_1(M->p0, M->edge1, M->edge2, M->n_faces, o, d, x, &face)) { r->mask[i] = 0; continue; }
+        }
+        if (M->interpolate) {
+            /* mesh_interpolate (:172-196): z and the normal from the C1 interpolants at (x, y) */
+            double c[3];
+            int start = (idx >= 0) ? M->ct_vertex_simplex[idx] : 0;
+            if (start < 0) start = 0;
+            int sx = ct_find_simplex(M, x, start, c);
+            double nn[3];
+            if (sx < 0) { x[2] = NAN; nn[0] = nn[1] = nn[2] = NAN; }
+            else {
+                x[2] = ct_eval(M, sx, c, 0);
+                for (int k = 0; k < 3; k++) nn[k] = ct_eval(M, sx, c, 1 + k);
+            }
+            double inv = 1.0 / norm3(nn);
+            for (int k = 0; k < 3; k++) r->nrm[3 * i + k] = inv * nn[k];
+        } else {
+            for (int k = 0; k < 3; k++) r->nrm[3 * i + k] = M->faces_normal[3 * face + k];
+        }
+    }
+}
+
 /* tools/xicsrt_aperture.py:108-204: single shape test on local coordinates */
 static int aperture_shape(const xrt_aperture_t* a, const double* X)
 {
@@ -871,6 +1066,7 @@ static void trace_optic(const xrt_optic_t* op, rays_t* r, mt_t* mt)
     case XRT_SHAPE_SPHERE:   intersect_sphere(op, r); break;
     case XRT_SHAPE_CYLINDER: intersect_cylinder(op, r); break;
     case XRT_SHAPE_TORUS:    intersect_torus(op, r); break;
+    case XRT_SHAPE_MESH:     intersect_mesh(op, r); break;
     }
     memcpy(r->hit, r->mask, (size_t)r->n);
     check_bounds(op, r);

@@ -298,6 +298,21 @@ def build_cases():
     add('F_plasma_trace', 'trace', cfg_three(0, sph, source=p, history=True, seed=61))
     add('F_plasma_counts', 'counts', cfg_three(0, sph, source=dict(p, emissivity=2e15 / 5),
                                                seed=61, runs=2))
+    # --- mesh set-up tables of the three generators (host-side parity) -----------
+    for cls, extra in [('XicsrtOpticMeshToroidalCrystal', {'radius_major': 1.0, 'radius_minor': 0.2, 'mesh_size': [9, 7]}),
+                       ('XicsrtOpticMeshSphericalCrystal', {'radius': 1.3, 'mesh_size': [8, 6]}),
+                       ('XicsrtOpticMeshCylindricalCrystal', {'radius': 0.9, 'mesh_size': [7, 9]})]:
+        c = _crystal(cls, **dict(_BRAGG, **extra))
+        add('T_tables_' + cls.replace('XicsrtOpticMesh', ''), 'mesh', cfg_three(10, c, seed=1))
+    c = _crystal('XicsrtOpticMeshToroidalCrystal', radius_major=1.0, radius_minor=0.2, mesh_size=[41, 41],
+                 **dict(_BRAGG, rocking_fwhm=2e-3))
+    add('E_mesh_interp_counts', 'counts', cfg_three(20000, c, seed=72, runs=2))
+    c = _crystal('XicsrtOpticMeshSphericalCrystal', radius=1.0, mesh_size=[21, 21], **dict(_BRAGG, check_bragg=False))
+    add('E_mesh_sphere_trace', 'trace', cfg_three(500, c, history=True, seed=73))
+    c = _crystal('XicsrtOpticMeshCylindricalCrystal', radius=1.0, mesh_size=[21, 21], mesh_interpolate=False,
+                 **dict(_BRAGG, check_bragg=False))
+    add('E_mesh_cylinder_trace', 'trace', cfg_three(500, c, history=True, seed=74))
+
     # --- mesh optics (BASELINE cfg5 shape, small) ---------------------------
     for interp in (False, True):
         c = _crystal('XicsrtOpticMeshToroidalCrystal', radius_major=1.0, radius_minor=0.2,
@@ -395,6 +410,32 @@ def dump_class_defaults():
     print('class_defaults.json:', {k: len(v) for k, v in out.items()})
 
 
+def run_mesh_tables(cfg):
+    """The set-up products of a mesh optic (generator output and _mesh_precalc tables)."""
+    cfg = copy.deepcopy(cfg)
+    obj = xicsrt.get_element(cfg, 'crystal')
+    out = {}
+    for key in ('mesh_points', 'mesh_normals', 'mesh_faces', 'mesh_coarse_points', 'mesh_coarse_normals',
+                'mesh_coarse_faces'):
+        out[key] = np.asarray(obj.param[key])
+    for which in ('mesh', 'mesh_coarse'):
+        m = obj.param[which]
+        out[which + '/faces_normal'] = np.asarray(m['faces_normal'])
+        out[which + '/p_faces_idx'] = np.asarray(m['p_faces_idx'])
+        out[which + '/p_faces_mask'] = np.asarray(m['p_faces_mask'])
+    tri = obj.param['mesh']['interp']['z'].tri
+    out['ct_simplices'] = np.asarray(tri.simplices)
+    out['ct_grad_z'] = np.asarray(obj.param['mesh']['interp']['z'].grad)
+    # Clough-Tocher values on a probe grid (third-party SciPy evaluated through the reference's objects)
+    xs = np.linspace(-0.08, 0.08, 9)
+    xx, yy = np.meshgrid(xs, xs * 0.9)
+    out['probe_xy'] = np.stack((xx.ravel(), yy.ravel())).T
+    out['probe_z'] = obj.param['mesh']['interp']['z'](xx.ravel(), yy.ravel())
+    out['probe_nx'] = obj.param['mesh']['interp']['normal_x'](xx.ravel(), yy.ravel())
+    out['names'] = np.array(['crystal'])
+    return out
+
+
 def run_history(cfg):
     """xicsrt.raytrace with keep_history=True: totals + found / lost ray histories."""
     cfg = copy.deepcopy(cfg)
@@ -428,7 +469,7 @@ def main(argv):
     for name in want:
         kind, cfg = cases[name]
         try:
-            out = {'trace': run_trace, 'counts': run_counts, 'history': run_history}[kind](cfg)
+            out = {'trace': run_trace, 'counts': run_counts, 'history': run_history, 'mesh': run_mesh_tables}[kind](cfg)
         except Exception as e:  # reference raised: record that, it is part of the contract
             print('%-32s REFERENCE RAISED %s: %s' % (name, type(e).__name__, e))
             continue

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 FLOAT_RTOL = 1e-12
 
 # features not on the device path yet (they must fail loudly, see test_host.py)
-NOT_ON_DEVICE = ('E_mesh',)
+NOT_ON_DEVICE = ('T_tables',)
 
 
 def _cases(kind):

@@ -21,6 +21,8 @@ def _jsonable(v):
         return v.tolist()
     if isinstance(v, dict):
         return {k: _jsonable(x) for k, x in v.items()}
+    if isinstance(v, (tuple, list)):
+        return [_jsonable(x) for x in v]
     return v
 
 
@@ -64,7 +66,7 @@ def test_strict_config_check_and_merge():
     with pytest.raises(Exception, match='Could not find XicsrtOpticNope'):
         xrt.find_class('XicsrtOpticNope', 'optics', [])
     with pytest.raises(NotImplementedError):
-        xrt.find_class('XicsrtOpticMeshToroidalCrystal', 'optics', [])
+        xrt.find_class('XicsrtOpticMeshMosaicCrystal', 'optics', [])
     with pytest.raises(ValueError, match='intensity of less than one'):
         xicsrt_amd.get_element({'sources': {'s': {'class_name': 'XicsrtSourceGeneric'}}}, 's')
 
@@ -154,6 +156,7 @@ def test_unsupported_scenes_fail_loudly():
     assert L.xrt_scene_check(flat.byref()) != 0
     assert b'trace_local' in L.xrt_last_error()
     cfg, gold = helpers.load_golden('E_mesh_flat_trace')
+    cfg['optics']['crystal']['class_name'] = 'XicsrtOpticMeshMosaicCrystal'
     with pytest.raises(NotImplementedError):
         helpers.build(cfg)
     cfg, gold = helpers.load_golden('F_plasma_trace')
@@ -167,11 +170,32 @@ def test_supported_scenes_validate():
     for name in ('A_example00_trace', 'B_mirror_trace', 'C_sphere_trace', 'D_CylindricalCrystal_trace',
                  'P_aperture2_trace', 'W_voigt_trace', 'S_focused_trace', 'G_flat_xy_trace',
                  'W_normal_trace', 'S_gaussian_spatial_trace', 'G_isotropic_xy_trace', 'Q_four_trace',
-                 'P_local_trace', 'M_spherical_mosaic_cutoff_trace', 'F_plasma_trace', 'D_ToroidalCrystal_trace'):
+                 'P_local_trace', 'M_spherical_mosaic_cutoff_trace', 'F_plasma_trace', 'D_ToroidalCrystal_trace',
+                 'E_mesh_flat_trace', 'E_mesh_interp_trace', 'E_mesh_sphere_trace', 'E_mesh_cylinder_trace'):
         cfg, gold = helpers.load_golden(name)
         config, elements, flat = helpers.build(cfg)
         assert L.xrt_scene_check(flat.byref()) == 0, (name, L.xrt_last_error())
         assert L.xrt_workspace_bytes(flat.byref(), 10) > 10 * 4096
+
+
+def test_mesh_tables_match_reference():
+    """Mesh generators and the pre-computed face / Clough-Tocher tables are bit-identical to the reference's
+    (optics/_ShapeMesh*.py; fixtures T_tables_* written by tests/golden/make_golden.py)."""
+    names = helpers.golden_names('mesh')
+    assert len(names) >= 3
+    for name in names:
+        cfg, gold = helpers.load_golden(name)
+        obj = xicsrt_amd.get_element(cfg, 'crystal')
+        for key in ('mesh_points', 'mesh_normals', 'mesh_faces', 'mesh_coarse_points', 'mesh_coarse_normals',
+                    'mesh_coarse_faces'):
+            assert np.array_equal(np.asarray(obj.param[key]), gold[key]), (name, key)
+        for which in ('mesh', 'mesh_coarse'):
+            tab = obj.param[which]
+            assert np.array_equal(tab['faces_normal'], gold[which + '/faces_normal']), (name, which)
+            assert np.array_equal(tab['p_faces_idx'], gold[which + '/p_faces_idx']), (name, which)
+            assert np.array_equal(tab['p_faces_mask'].astype(bool), gold[which + '/p_faces_mask'].astype(bool)), (name, which)
+        assert np.array_equal(obj.param['mesh']['ct_simplices'], gold['ct_simplices'])
+        assert np.array_equal(obj.param['mesh']['ct_grad'][0], gold['ct_grad_z'][:, 0, :])
 
 
 def test_product_does_not_reference_the_oracle():

@@ -9,7 +9,7 @@ import pytest
 import helpers
 
 # golden cases whose features the oracle / device path implement so far
-SKIP_PREFIX = ('E_mesh', 'H_history')
+SKIP_PREFIX = ('H_history', 'T_tables')
 
 
 def _cases(kind):

@@ -76,6 +76,17 @@ struct KSource {
     int32_t use_poisson, pad2;
 };
 
+struct KMesh {               // device pointers, see xrt_mesh_t
+    int32_t n_points, n_faces, n_coarse_faces, interpolate, n_simplices, pad;
+    const double *points, *p0, *p1, *p2, *edge1, *edge2, *faces_normal, *faces_area;
+    const int32_t* p_faces_idx;
+    const uint8_t* p_faces_mask;
+    const double *c_p0, *c_edge1, *c_edge2;
+    const int32_t *ct_simplices, *ct_neighbors;
+    const double *ct_transform, *ct_points, *ct_values, *ct_grad;
+    const int32_t* ct_vertex_simplex;
+};
+
 struct KOptic {
     int32_t shape, interact, flags, rocking_type;
     double  origin[3];
@@ -94,6 +105,7 @@ struct KOptic {
     int32_t pixel_nx, pixel_ny;
     int64_t image_offset;
     const xrt_aperture_t* apertures;    // device
+    const KMesh* mesh;                  // device (XRT_SHAPE_MESH)
     int32_t n_apertures;
     int32_t pad;
 };
@@ -515,6 +527,181 @@ __device__ __forceinline__ V3 surface_normal(const KOptic& op, const V3& X)
         nrm.x = c.x / m; nrm.y = c.y / m; nrm.z = c.z / m;
     }
     return nrm;
+}
+
+// ---- mesh optics (optics/_ShapeMesh.py), rays already in the optic's frame -------------------
+
+// Moller-Trumbore over every face, later faces overwrite earlier hits (:289-348).  The two
+// 'i,ji->j' products go through BLAS in the reference (fused order), the others are numpy's own.
+__device__ bool mesh_intersect_1(const double* P0, const double* E1, const double* E2, int nf, const Ray& ray, V3& X, int& face)
+{
+    const double epsilon = 1e-15;
+    bool hit = false;
+    for (int ii = 0; ii < nf; ii++) {
+        const V3 p0 = ld3(P0 + 3 * ii), e1 = ld3(E1 + 3 * ii), e2 = ld3(E2 + 3 * ii);
+        const V3 h = cross3(ray.d, e2);
+        double f = dot_blas(h, e1);
+        if ((f > -epsilon) && (f < epsilon)) continue;
+        f = 1.0 / f;
+        const V3 s = sub3(ray.o, p0);
+        const double u = f * dot_e(s, h);
+        if ((u < 0.0) || (u > 1.0)) continue;
+        const V3 q = cross3(s, e1);
+        const double v = f * dot_e(ray.d, q);
+        if ((v < 0.0) || (u + v > 1.0)) continue;
+        const double t = f * dot_blas(q, e2);
+        hit = true;
+        face = ii;
+        X.x = ray.o.x + t * ray.d.x; X.y = ray.o.y + t * ray.d.y; X.z = ray.o.z + t * ray.d.z;
+    }
+    return hit;
+}
+
+// cKDTree(points).query(x)[1] (:464-475): nearest fine-mesh point, first minimum
+__device__ int mesh_nearest(const KMesh& M, const V3& x)
+{
+    int best = 0;
+    double bd = __builtin_inf();
+    for (int i = 0; i < M.n_points; i++) {
+        const double dx = x.x - M.points[3 * i], dy = x.y - M.points[3 * i + 1], dz = x.z - M.points[3 * i + 2];
+        const double d = (dx * dx + dy * dy) + dz * dz;
+        if (d < bd) { bd = d; best = i; }
+    }
+    return best;
+}
+
+// the <= 8 faces around the nearest point: plane hit + area-sum test, first passing (:350-426)
+__device__ bool mesh_intersect_2(const KMesh& M, int idx, const Ray& ray, V3& X, int& face)
+{
+    for (int k = 0; k < 8; k++) {
+        const int f = M.p_faces_idx[k * M.n_points + idx];
+        const bool valid = M.p_faces_mask[k * M.n_points + idx] != 0;
+        const V3 p0 = ld3(M.p0 + 3 * f), p1 = ld3(M.p1 + 3 * f), p2 = ld3(M.p2 + 3 * f), n = ld3(M.faces_normal + 3 * f);
+        const V3 t0 = sub3(p0, ray.o);
+        const double t1 = dot_e(t0, n), t2 = dot_e(ray.d, n);
+        const double dist = t1 / t2;
+        V3 I;
+        I.x = ray.d.x * dist + ray.o.x; I.y = ray.d.y * dist + ray.o.y; I.z = ray.d.z * dist + ray.o.z;
+        const V3 a = sub3(I, p0), b = sub3(I, p1), c = sub3(I, p2);
+        const double diff = ((norm3(cross3(b, c)) + norm3(cross3(c, a))) + norm3(cross3(a, b))) - M.faces_area[f];
+        if ((diff < 1e-10) && (dist >= 0) && valid) { X = I; face = f; return true; }
+    }
+    return false;
+}
+
+// SciPy CloughTocher2DInterpolator (third party, scipy 1.15.3): barycentric walk + the cubic
+// Bezier evaluation of _clough_tocher_2d_single with affine-invariant edge directions.
+__device__ __forceinline__ void ct_bary(const double* T, double x0, double x1, double* c)
+{
+    c[2] = 1.0;
+    c[0] = 0.0; c[0] += T[0] * (x0 - T[4]); c[0] += T[1] * (x1 - T[5]); c[2] -= c[0];
+    c[1] = 0.0; c[1] += T[2] * (x0 - T[4]); c[1] += T[3] * (x1 - T[5]); c[2] -= c[1];
+}
+
+__device__ int ct_find_simplex(const KMesh& M, double x0, double x1, int start, double* c)
+{
+    const double eps = 100 * 2.220446049250313e-16;
+    if (x0 != x0 || x1 != x1) return -1;
+    int s = start;
+    for (int iter = 0; iter < M.n_simplices + 8; iter++) {
+        ct_bary(M.ct_transform + 6 * s, x0, x1, c);
+        int worst = -1;
+        double wv = -eps;
+        for (int k = 0; k < 3; k++) if (c[k] < wv) { wv = c[k]; worst = k; }
+        if (worst < 0) return s;
+        const int nb = M.ct_neighbors[3 * s + worst];
+        if (nb < 0) break;
+        s = nb;
+    }
+    for (s = 0; s < M.n_simplices; s++) {
+        ct_bary(M.ct_transform + 6 * s, x0, x1, c);
+        if (c[0] >= -eps && c[1] >= -eps && c[2] >= -eps) return s;
+    }
+    return -1;
+}
+
+__device__ double ct_eval(const KMesh& M, int isimplex, const double* b, int which)
+{
+    const int* v = M.ct_simplices + 3 * isimplex;
+    const double* pts = M.ct_points;
+    const double* val = M.ct_values + (size_t)which * M.n_points;
+    const double* grd = M.ct_grad + (size_t)which * M.n_points * 2;
+    const double e12x = pts[2 * v[1]] - pts[2 * v[0]], e12y = pts[2 * v[1] + 1] - pts[2 * v[0] + 1];
+    const double e23x = pts[2 * v[2]] - pts[2 * v[1]], e23y = pts[2 * v[2] + 1] - pts[2 * v[1] + 1];
+    const double e31x = pts[2 * v[0]] - pts[2 * v[2]], e31y = pts[2 * v[0] + 1] - pts[2 * v[2] + 1];
+    const double f1 = val[v[0]], f2 = val[v[1]], f3 = val[v[2]];
+    const double* d1 = grd + 2 * v[0]; const double* d2 = grd + 2 * v[1]; const double* d3 = grd + 2 * v[2];
+    const double df12 = +(d1[0] * e12x + d1[1] * e12y);
+    const double df21 = -(d2[0] * e12x + d2[1] * e12y);
+    const double df23 = +(d2[0] * e23x + d2[1] * e23y);
+    const double df32 = -(d3[0] * e23x + d3[1] * e23y);
+    const double df31 = +(d3[0] * e31x + d3[1] * e31y);
+    const double df13 = -(d1[0] * e31x + d1[1] * e31y);
+    const double c3000 = f1, c2100 = (df12 + 3 * c3000) / 3, c2010 = (df13 + 3 * c3000) / 3;
+    const double c0300 = f2, c1200 = (df21 + 3 * c0300) / 3, c0210 = (df23 + 3 * c0300) / 3;
+    const double c0030 = f3, c1020 = (df31 + 3 * c0030) / 3, c0120 = (df32 + 3 * c0030) / 3;
+    const double c2001 = (c2100 + c2010 + c3000) / 3;
+    const double c0201 = (c1200 + c0300 + c0210) / 3;
+    const double c0021 = (c1020 + c0120 + c0030) / 3;
+    double g[3];
+    for (int k = 0; k < 3; k++) {
+        const int itri = M.ct_neighbors[3 * isimplex + k];
+        if (itri == -1) { g[k] = -1. / 2; continue; }
+        const int* w = M.ct_simplices + 3 * itri;
+        double c[3];
+        const double y0 = (pts[2 * w[0]] + pts[2 * w[1]] + pts[2 * w[2]]) / 3;
+        const double y1 = (pts[2 * w[0] + 1] + pts[2 * w[1] + 1] + pts[2 * w[2] + 1]) / 3;
+        ct_bary(M.ct_transform + 6 * isimplex, y0, y1, c);
+        if (k == 0)      g[k] = (2 * c[2] + c[1] - 1) / (2 - 3 * c[2] - 3 * c[1]);
+        else if (k == 1) g[k] = (2 * c[0] + c[2] - 1) / (2 - 3 * c[0] - 3 * c[2]);
+        else             g[k] = (2 * c[1] + c[0] - 1) / (2 - 3 * c[1] - 3 * c[0]);
+    }
+    const double c0111 = (g[0] * (-c0300 + 3 * c0210 - 3 * c0120 + c0030) + (-c0300 + 2 * c0210 - c0120 + c0021 + c0201)) / 2;
+    const double c1011 = (g[1] * (-c0030 + 3 * c1020 - 3 * c2010 + c3000) + (-c0030 + 2 * c1020 - c2010 + c2001 + c0021)) / 2;
+    const double c1101 = (g[2] * (-c3000 + 3 * c2100 - 3 * c1200 + c0300) + (-c3000 + 2 * c2100 - c1200 + c2001 + c0201)) / 2;
+    const double c1002 = (c1101 + c1011 + c2001) / 3;
+    const double c0102 = (c1101 + c0111 + c0201) / 3;
+    const double c0012 = (c1011 + c0111 + c0021) / 3;
+    const double c0003 = (c1002 + c0102 + c0012) / 3;
+    double minval = b[0];
+    for (int k = 0; k < 3; k++) if (b[k] < minval) minval = b[k];
+    const double b1 = b[0] - minval, b2 = b[1] - minval, b3 = b[2] - minval, b4 = 3 * minval;
+    return (pow(b1, 3) * c3000 + 3 * pow(b1, 2) * b2 * c2100 + 3 * pow(b1, 2) * b3 * c2010 + 3 * pow(b1, 2) * b4 * c2001 +
+            3 * b1 * pow(b2, 2) * c1200 + 6 * b1 * b2 * b4 * c1101 + 3 * b1 * pow(b3, 2) * c1020 + 6 * b1 * b3 * b4 * c1011 +
+            3 * b1 * pow(b4, 2) * c1002 + pow(b2, 3) * c0300 + 3 * pow(b2, 2) * b3 * c0210 + 3 * pow(b2, 2) * b4 * c0201 +
+            3 * b2 * pow(b3, 2) * c0120 + 6 * b2 * b3 * b4 * c0111 + 3 * b2 * pow(b4, 2) * c0102 + pow(b3, 3) * c0030 +
+            3 * pow(b3, 2) * b4 * c0021 + 3 * b3 * pow(b4, 2) * c0012 + pow(b4, 3) * c0003);
+}
+
+// ShapeMesh.intersect (:135-170): intersection point and surface normal together
+__device__ bool mesh_intersect(const KMesh& M, const Ray& ray, V3& X, V3& nrm)
+{
+    int face = 0, idx = -1;
+    if (M.n_coarse_faces > 0) {
+        V3 xc;
+        if (!mesh_intersect_1(M.c_p0, M.c_edge1, M.c_edge2, M.n_coarse_faces, ray, xc, face)) return false;
+        idx = mesh_nearest(M, xc);
+        if (!mesh_intersect_2(M, idx, ray, X, face)) return false;
+    } else {
+        if (!mesh_intersect_1(M.p0, M.edge1, M.edge2, M.n_faces, ray, X, face)) return false;
+    }
+    if (M.interpolate) {
+        double c[3];
+        int start = (idx >= 0) ? M.ct_vertex_simplex[idx] : 0;
+        if (start < 0) start = 0;
+        const int sx = ct_find_simplex(M, X.x, X.y, start, c);
+        V3 nn;
+        if (sx < 0) { X.z = __builtin_nan(""); nn.x = nn.y = nn.z = __builtin_nan(""); }
+        else {
+            X.z = ct_eval(M, sx, c, 0);
+            nn.x = ct_eval(M, sx, c, 1); nn.y = ct_eval(M, sx, c, 2); nn.z = ct_eval(M, sx, c, 3);
+        }
+        const double inv = 1.0 / norm3(nn);
+        nrm.x = inv * nn.x; nrm.y = inv * nn.y; nrm.z = inv * nn.z;
+    } else {
+        nrm = ld3(M.faces_normal + 3 * face);
+    }
+    return true;
 }
 
 // tools/xicsrt_aperture.py:108-204
@@ -1233,8 +1420,15 @@ extern "C" int xrt_scene_check(const xrt_scene_t* sc)
         return fail(-2, "%s", "voigt table missing");
     for (int e = 0; e < sc->n_optics; e++) {
         const xrt_optic_t& o = sc->optics[e];
-        if (o.shape < XRT_SHAPE_PLANE || o.shape > XRT_SHAPE_TORUS)
+        if (o.shape < XRT_SHAPE_PLANE || o.shape > XRT_SHAPE_MESH)
             return fail(-3, "%s", "optic shape is not implemented on the device path");
+        if (o.shape == XRT_SHAPE_MESH) {
+            const xrt_mesh_t* m = o.mesh;
+            if (!m || m->n_points < 3 || m->n_faces < 1 || !m->points || !m->p0 || !m->faces_normal || !m->p_faces_idx)
+                return fail(-2, "%s", "mesh tables missing");
+            if (m->interpolate && (m->n_simplices < 1 || !m->ct_simplices || !m->ct_grad)) return fail(-2, "%s", "mesh interpolation tables missing");
+            if (o.interact == XRT_INTERACT_MOSAIC) return fail(-3, "%s", "mesh mosaic crystals are not implemented on the device path");
+        }
         if (o.shape == XRT_SHAPE_TORUS && (o.torus_root < 0 || o.torus_root > 3))
             return fail(-2, "%s", "torus root index out of range");
         if (o.interact < XRT_INTERACT_NONE || o.interact > XRT_INTERACT_MOSAIC)
@@ -1286,6 +1480,7 @@ static bool needs_staged(const xrt_scene_t* sc)
     for (int e = 0; e < sc->n_optics; e++) {
         if (sc->optics[e].interact == XRT_INTERACT_MOSAIC) return true;     // whole-array passes per layer
         if (sc->optics[e].flags & XRT_F_TRACE_LOCAL) return true;
+        if (sc->optics[e].shape == XRT_SHAPE_MESH) return true;
         if (sc->optics[e].interact == XRT_INTERACT_CRYSTAL && (sc->optics[e].flags & XRT_F_CHECK_BRAGG)) n_bragg++;
     }
     return n_bragg > 1;
@@ -1294,6 +1489,23 @@ static bool needs_staged(const xrt_scene_t* sc)
 static int staged_slots(int n_runs) { return n_runs < XRT_ST_SLOTS ? (n_runs < 1 ? 1 : n_runs) : XRT_ST_SLOTS; }
 static size_t ws_off_gauss(const xrt_scene_t* sc, int n_runs) { return al256(ws_off_polys(sc, n_runs) + sizeof(uint32_t) * 624 * (XRT_MAX_HEADS + 1)); }
 static size_t ws_off_staged(const xrt_scene_t* sc, int n_runs) { return al256(ws_off_gauss(sc, n_runs) + sizeof(KState) * (size_t)n_runs); }
+// bytes of one mesh's tables on the device (each array 256-byte aligned) + its KMesh header
+static size_t mesh_bytes(const xrt_mesh_t* m)
+{
+    if (!m) return 0;
+    size_t b = al256(sizeof(KMesh));
+    const size_t P = (size_t)m->n_points, F = (size_t)m->n_faces, Cn = (size_t)m->n_coarse_faces, T = (size_t)m->n_simplices;
+    b += al256(P * 3 * 8) + 7 * al256(F * 3 * 8) + al256(P * 8 * 4) + al256(P * 8) + 3 * al256(Cn * 3 * 8 + 8);
+    if (m->interpolate) b += 2 * al256(T * 3 * 4) + al256(T * 6 * 8) + al256(P * 2 * 8) + al256(4 * P * 8) + al256(8 * P * 8) + al256(P * 4);
+    return b;
+}
+static size_t meshes_bytes(const xrt_scene_t* sc)
+{
+    size_t b = 0;
+    for (int e = 0; e < sc->n_optics; e++) if (sc->optics[e].shape == XRT_SHAPE_MESH) b += mesh_bytes(sc->optics[e].mesh);
+    return b;
+}
+
 static size_t staged_bytes(const xrt_scene_t* sc, int n_runs)
 {
     if (!needs_staged(sc)) return 0;
@@ -1306,7 +1518,7 @@ extern "C" size_t xrt_workspace_bytes(const xrt_scene_t* sc, int32_t n_runs)
 {
     if (!sc || n_runs < 0) return 0;
     if (n_runs < 1) n_runs = 1;
-    return ws_off_staged(sc, n_runs) + staged_bytes(sc, n_runs) + 256;
+    return ws_off_staged(sc, n_runs) + staged_bytes(sc, n_runs) + meshes_bytes(sc) + 256;
 }
 
 static bool needs_full(const xrt_scene_t* sc)
@@ -1398,6 +1610,52 @@ static size_t lds_bytes(int n_src_heads)
     return (b + 15) & ~(size_t)15;
 }
 
+// device copy of every mesh's tables behind the staged region; fills KOptic.mesh
+static int upload_meshes(const xrt_scene_t* sc, char* ws, int n_runs, KScene* ks, hipStream_t stream)
+{
+    char* base = ws + ws_off_staged(sc, n_runs) + staged_bytes(sc, n_runs);
+    for (int e = 0; e < sc->n_optics; e++) {
+        ks->opt[e].mesh = nullptr;
+        if (sc->optics[e].shape != XRT_SHAPE_MESH) continue;
+        const xrt_mesh_t* m = sc->optics[e].mesh;
+        static thread_local KMesh hk[XRT_DEV_MAX_OPTICS];
+        KMesh& k = hk[e];
+        memset(&k, 0, sizeof(k));
+        k.n_points = m->n_points; k.n_faces = m->n_faces; k.n_coarse_faces = m->n_coarse_faces;
+        k.interpolate = m->interpolate; k.n_simplices = m->n_simplices;
+        char* p = base + al256(sizeof(KMesh));
+        auto put = [&](const void* src, size_t bytes) -> const void* {
+            char* dst = p;
+            p += al256(bytes > 0 ? bytes : 8);
+            if (src && bytes) (void)hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream);
+            return dst;
+        };
+        const size_t P = (size_t)m->n_points, F = (size_t)m->n_faces, Cn = (size_t)m->n_coarse_faces, T = (size_t)m->n_simplices;
+        k.points = (const double*)put(m->points, P * 24);
+        k.p0 = (const double*)put(m->p0, F * 24); k.p1 = (const double*)put(m->p1, F * 24); k.p2 = (const double*)put(m->p2, F * 24);
+        k.edge1 = (const double*)put(m->edge1, F * 24); k.edge2 = (const double*)put(m->edge2, F * 24);
+        k.faces_normal = (const double*)put(m->faces_normal, F * 24);
+        k.faces_area = (const double*)put(m->faces_area, F * 8);
+        k.p_faces_idx = (const int32_t*)put(m->p_faces_idx, P * 32);
+        k.p_faces_mask = (const uint8_t*)put(m->p_faces_mask, P * 8);
+        k.c_p0 = (const double*)put(m->c_p0, Cn * 24); k.c_edge1 = (const double*)put(m->c_edge1, Cn * 24);
+        k.c_edge2 = (const double*)put(m->c_edge2, Cn * 24);
+        if (m->interpolate) {
+            k.ct_simplices = (const int32_t*)put(m->ct_simplices, T * 12);
+            k.ct_neighbors = (const int32_t*)put(m->ct_neighbors, T * 12);
+            k.ct_transform = (const double*)put(m->ct_transform, T * 48);
+            k.ct_points = (const double*)put(m->ct_points, P * 16);
+            k.ct_values = (const double*)put(m->ct_values, 4 * P * 8);
+            k.ct_grad = (const double*)put(m->ct_grad, 8 * P * 8);
+            k.ct_vertex_simplex = (const int32_t*)put(m->ct_vertex_simplex, P * 4);
+        }
+        HIP_TRY(hipMemcpyAsync(base, &k, sizeof(KMesh), hipMemcpyHostToDevice, stream));
+        ks->opt[e].mesh = reinterpret_cast<const KMesh*>(base);
+        base += mesh_bytes(m);
+    }
+    return 0;
+}
+
 // uploads of the small tables (pageable host memory -> staged copies, ordered on the stream)
 static int upload_tables(const xrt_scene_t* sc, char* ws, hipStream_t stream)
 {
@@ -1467,7 +1725,7 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
         a.streams = streams; a.heads = heads; a.n_runs = n_runs; a.n_src_heads = nh;
         a.run_counter = reinterpret_cast<uint32_t*>(ws);
         HIP_TRY(hipMemsetAsync(ws, 0, 64, stream));
-        const size_t lds = sizeof(double) * XRT_TILE_COMP * XRT_TILE + sizeof(uint32_t) * (XRT_TILE + XRT_RING + 64);
+        const size_t lds = sizeof(double) * 10 * XRT_TILE + sizeof(uint32_t) * (XRT_TILE + XRT_RING + 64);
         int ti = -1;
         if (timing_on && timing_n < TIMING_MAX) {
             ti = timing_n++;
@@ -1548,6 +1806,8 @@ extern "C" int xrt_trace(const xrt_scene_t* sc, const uint32_t* seeds, int32_t n
     HIP_TRY(hipMemsetAsync(ws + 64, 0, 64, stream));           // status word
     KScene ks;
     build_kscene(sc, ws, &ks);
+    st = upload_meshes(sc, ws, n_runs, &ks, stream);
+    if (st) return st;
     KArgs a;
     memset(&a, 0, sizeof(a));
     a.num_out = reinterpret_cast<unsigned long long*>(num_out);
@@ -1584,6 +1844,8 @@ extern "C" int xrt_trace_history(const xrt_scene_t* sc, const xrt_rng_state_t* s
     HIP_TRY(hipMemsetAsync(ws + 64, 0, 64, stream));           // status word
     KScene ks;
     build_kscene(sc, ws, &ks);
+    st = upload_meshes(sc, ws, 1, &ks, stream);
+    if (st) return st;
     KArgs a;
     memset(&a, 0, sizeof(a));
     a.num_out = reinterpret_cast<unsigned long long*>(num_out);

@@ -228,6 +228,16 @@ _ELEMENTS = (
     ('XicsrtOpticSphericalMosaicCrystal', InteractMosaicCrystal, ShapeSphere),
 )
 
+from .mesh import ShapeMesh, ShapeMeshSphere, ShapeMeshCylinder, ShapeMeshTorus  # noqa: E402
+
+_ELEMENTS = _ELEMENTS + (
+    ('XicsrtOpticMeshMirror', InteractMirror, ShapeMesh),
+    ('XicsrtOpticMeshCrystal', InteractCrystal, ShapeMesh),
+    ('XicsrtOpticMeshSphericalCrystal', InteractCrystal, ShapeMeshSphere),
+    ('XicsrtOpticMeshCylindricalCrystal', InteractCrystal, ShapeMeshCylinder),
+    ('XicsrtOpticMeshToroidalCrystal', InteractCrystal, ShapeMeshTorus),
+)
+
 BUILTIN = {}
 for _name, _interact, _shape in _ELEMENTS:
     _cls = type(_name, (_interact, _shape), {
@@ -239,7 +249,5 @@ del _name, _interact, _shape, _cls
 
 # Known reference element classes that the device path does not implement yet.
 NOT_IMPLEMENTED = (
-    'XicsrtOpticMeshCrystal', 'XicsrtOpticMeshMirror', 'XicsrtOpticMeshMosaicCrystal',
-    'XicsrtOpticMeshSphericalCrystal', 'XicsrtOpticMeshCylindricalCrystal',
-    'XicsrtOpticMeshToroidalCrystal',
+    'XicsrtOpticMeshMosaicCrystal',
 )

@@ -20,7 +20,7 @@ import ctypes as C
 
 import numpy as np
 
-XRT_ABI_VERSION = 8
+XRT_ABI_VERSION = 9
 XRT_MAX_OPTICS = 16
 XRT_MAX_APERTURES = 8
 XRT_HIST_COMPONENTS = 8
@@ -29,7 +29,7 @@ SRC_KIND = {'zaxis': 0, 'direction': 1, 'target': 2, 'plasma': 3}
 SPATIAL = {'uniform': 0, 'gaussian': 1}
 ANGULAR = {'isotropic': 0, 'isotropic_xy': 1, 'flat': 2, 'flat_xy': 3}
 WL_CONST, WL_UNIFORM, WL_NORMAL, WL_VOIGT = 0, 1, 2, 3
-SHAPE = {'plane': 0, 'sphere': 1, 'cylinder': 2, 'torus': 3}
+SHAPE = {'plane': 0, 'sphere': 1, 'cylinder': 2, 'torus': 3, 'mesh': 4}
 INTERACT = {'none': 0, 'mirror': 1, 'crystal': 2, 'mosaic': 3}
 ROCKING_STEP, ROCKING_GAUSS = 0, 1
 AP_SHAPE = {'none': 0, 'circle': 1, 'square': 2, 'rectangle': 3, 'ellipse': 4, 'triangle': 5}
@@ -62,6 +62,19 @@ class Source(C.Structure):
                 ('bundle_intensity', C.c_double), ('use_poisson', C.c_int32), ('pad_plasma', C.c_int32)]
 
 
+_PD, _PI, _PB = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
+
+
+class Mesh(C.Structure):
+    _fields_ = [('n_points', C.c_int32), ('n_faces', C.c_int32), ('n_coarse_faces', C.c_int32),
+                ('interpolate', C.c_int32), ('n_simplices', C.c_int32), ('pad', C.c_int32),
+                ('points', _PD), ('p0', _PD), ('p1', _PD), ('p2', _PD), ('edge1', _PD), ('edge2', _PD),
+                ('faces_normal', _PD), ('faces_area', _PD), ('p_faces_idx', _PI), ('p_faces_mask', _PB),
+                ('c_p0', _PD), ('c_edge1', _PD), ('c_edge2', _PD),
+                ('ct_simplices', _PI), ('ct_neighbors', _PI), ('ct_transform', _PD), ('ct_points', _PD),
+                ('ct_values', _PD), ('ct_grad', _PD), ('ct_vertex_simplex', _PI)]
+
+
 class Optic(C.Structure):
     _fields_ = [('shape', C.c_int32), ('interact', C.c_int32),
                 ('flags', C.c_int32), ('rocking_type', C.c_int32),
@@ -77,7 +90,7 @@ class Optic(C.Structure):
                 ('mosaic_cutoff_angle', C.c_double), ('mosaic_A', C.c_double * 4),
                 ('pixel_size', C.c_double), ('pixel_xoff', C.c_double), ('pixel_yoff', C.c_double),
                 ('pixel_nx', C.c_int32), ('pixel_ny', C.c_int32),
-                ('image_offset', C.c_int64),
+                ('image_offset', C.c_int64), ('mesh', C.POINTER(Mesh)),
                 ('apertures', Aperture * XRT_MAX_APERTURES)]
 
 
@@ -336,9 +349,51 @@ def _aperture_list(info):
     return list(info)
 
 
-def flatten_optic(obj, out, image_offset):
+def flatten_mesh(obj, keep):
+    """ShapeMesh tables -> Mesh struct (host pointers into arrays pinned in `keep`)."""
+    p = obj.param
+    fine = p['mesh']
+    m = Mesh()
+
+    def ptr(arr, dtype, ctype):
+        arr = np.ascontiguousarray(arr, dtype=dtype)
+        keep.append(arr)
+        return arr.ctypes.data_as(C.POINTER(ctype))
+
+    m.n_points, m.n_faces = len(fine['points']), len(fine['faces'])
+    m.interpolate = int(bool(p['mesh_interpolate']))
+    m.points = ptr(fine['points'], np.float64, C.c_double)
+    for key in ('p0', 'p1', 'p2', 'edge1', 'edge2', 'faces_normal', 'faces_area'):
+        setattr(m, key, ptr(fine[key], np.float64, C.c_double))
+    m.p_faces_idx = ptr(fine['p_faces_idx'], np.int32, C.c_int32)
+    m.p_faces_mask = ptr(fine['p_faces_mask'], np.uint8, C.c_uint8)
+    m.n_coarse_faces = 0
+    if p['mesh_refine']:
+        coarse = p['mesh_coarse']
+        m.n_coarse_faces = len(coarse['faces'])
+        m.c_p0 = ptr(coarse['p0'], np.float64, C.c_double)
+        m.c_edge1 = ptr(coarse['edge1'], np.float64, C.c_double)
+        m.c_edge2 = ptr(coarse['edge2'], np.float64, C.c_double)
+    m.n_simplices = 0
+    if m.interpolate:
+        m.n_simplices = len(fine['ct_simplices'])
+        m.ct_simplices = ptr(fine['ct_simplices'], np.int32, C.c_int32)
+        m.ct_neighbors = ptr(fine['ct_neighbors'], np.int32, C.c_int32)
+        m.ct_transform = ptr(fine['ct_transform'], np.float64, C.c_double)
+        m.ct_points = ptr(fine['ct_points'], np.float64, C.c_double)
+        m.ct_values = ptr(fine['ct_values'], np.float64, C.c_double)
+        m.ct_grad = ptr(fine['ct_grad'], np.float64, C.c_double)
+        m.ct_vertex_simplex = ptr(fine['ct_vertex_simplex'], np.int32, C.c_int32)
+    keep.append(m)
+    return m
+
+
+def flatten_optic(obj, out, image_offset, keep=None):
     """Fill an Optic struct from an initialised XicsrtOptic* object; returns bins used."""
     p = obj.param
+    out.mesh = None
+    if obj.shape_kind == 'mesh':
+        out.mesh = C.pointer(flatten_mesh(obj, keep))
     if obj.shape_kind not in SHAPE or obj.interact_kind not in INTERACT:
         raise SceneError('optic %s is not implemented on the device path' % obj.name)
     out.shape = SHAPE[obj.shape_kind]
@@ -478,7 +533,7 @@ class FlatScene:
         offset = 0
         self.image_slices = {}
         for k, (name, obj) in enumerate(zip(self.names[1:], optic_objs)):
-            bins = flatten_optic(obj, self.struct.optics[k], offset)
+            bins = flatten_optic(obj, self.struct.optics[k], offset, self._keep)
             if bins:
                 o = self.struct.optics[k]
                 self.image_slices[name] = (offset, o.pixel_nx, o.pixel_ny)
