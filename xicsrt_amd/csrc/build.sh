@@ -2,11 +2,14 @@
 # Builds libxicsrt_hip.so for gfx950 (MI355X) in-tree.  hipcc cross-compiles
 # without a GPU.  -ffp-contract=off: the reference (NumPy) evaluates a*b+c with
 # two roundings; fused multiply-adds appear only where written explicitly.
+# -instcombine-max-copied-from-constant-users: the scene is a ~3.6 KB by-value kernel argument
+# read through scalar loads; above 300 uses LLVM would otherwise keep a per-lane private copy.
 set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared \
     -ffp-contract=off -fno-fast-math \
+    -mllvm -instcombine-max-copied-from-constant-users=10000 \
     -Wall -Wno-unused-function \
     ${XRT_EXTRA_FLAGS} \
     -o libxicsrt_hip.so xrt_kernels.hip

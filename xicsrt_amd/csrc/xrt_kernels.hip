@@ -33,6 +33,8 @@
 #include <stdio.h>
 #include <math.h>
 #include <stdlib.h>
+#include <cmath>
+#include <vector>
 
 #include "../../include/xicsrt_hip.h"
 
@@ -85,6 +87,12 @@ struct KMesh {               // device pointers, see xrt_mesh_t
     const int32_t *ct_simplices, *ct_neighbors;
     const double *ct_transform, *ct_points, *ct_values, *ct_grad;
     const int32_t* ct_vertex_simplex;
+    // x-y bucket grid over the points for the exact nearest-point search (built by the library)
+    int32_t grid_nx, grid_ny;
+    double  grid_x0, grid_y0, grid_hx, grid_hy, grid_ihx, grid_ihy, grid_tiny;
+    const int32_t* cell_start;      // [nx*ny + 1]
+    const int32_t* cell_idx;        // [n_points] point indices bucket by bucket, ascending inside a bucket
+    const double*  cell_xyz;        // [n_points][3] the points in that order
 };
 
 struct KOptic {
@@ -557,17 +565,56 @@ __device__ bool mesh_intersect_1(const double* P0, const double* E1, const doubl
     return hit;
 }
 
-// cKDTree(points).query(x)[1] (:464-475): nearest fine-mesh point, first minimum
+// cKDTree(points).query(x)[1] (:464-475): the nearest fine-mesh point (exact; lowest index on an
+// exact tie).  Ring search over the x-y buckets: after ring r every point outside the (2r+1)^2
+// block is at least `bound` away in x-y, hence in 3D; stop when the best distance beats that.
 __device__ int mesh_nearest(const KMesh& M, const V3& x)
 {
     int best = 0;
     double bd = __builtin_inf();
-    for (int i = 0; i < M.n_points; i++) {
-        const double dx = x.x - M.points[3 * i], dy = x.y - M.points[3 * i + 1], dz = x.z - M.points[3 * i + 2];
-        const double d = (dx * dx + dy * dy) + dz * dz;
-        if (d < bd) { bd = d; best = i; }
+    if (M.grid_nx <= 0) {
+        for (int i = 0; i < M.n_points; i++) {
+            const double dx = x.x - M.points[3 * i], dy = x.y - M.points[3 * i + 1], dz = x.z - M.points[3 * i + 2];
+            const double d = (dx * dx + dy * dy) + dz * dz;
+            if (d < bd) { bd = d; best = i; }
+        }
+        return best;
     }
-    return best;
+    const int nx = M.grid_nx, ny = M.grid_ny;
+    double fx = floor((x.x - M.grid_x0) * M.grid_ihx), fy = floor((x.y - M.grid_y0) * M.grid_ihy);
+    if (!(fx >= 0.0)) fx = 0.0;
+    if (!(fy >= 0.0)) fy = 0.0;
+    const int cx = fx > (double)(nx - 1) ? nx - 1 : (int)fx, cy = fy > (double)(ny - 1) ? ny - 1 : (int)fy;
+    best = -1;
+    const int rmax = nx > ny ? nx : ny;
+    for (int r = 0; r <= rmax; r++) {
+        const int xlo = cx - r, xhi = cx + r, ylo = cy - r, yhi = cy + r;
+        const int ya = ylo < 0 ? 0 : ylo, yb = yhi > ny - 1 ? ny - 1 : yhi;
+        for (int yy = ya; yy <= yb; yy++) {
+            const bool whole_row = (yy == ylo) || (yy == yhi);
+            const int step = (whole_row || r == 0) ? 1 : 2 * r;
+            for (int xx = xlo; xx <= xhi; xx += step) {
+                if (xx < 0 || xx >= nx) continue;
+                const int c = yy * nx + xx;
+                const int c0 = M.cell_start[c], c1 = M.cell_start[c + 1];
+                for (int k = c0; k < c1; k++) {
+                    const double dx = x.x - M.cell_xyz[3 * k], dy = x.y - M.cell_xyz[3 * k + 1], dz = x.z - M.cell_xyz[3 * k + 2];
+                    const double d = (dx * dx + dy * dy) + dz * dz;
+                    const int i = M.cell_idx[k];
+                    if (d < bd || (d == bd && i < best)) { bd = d; best = i; }
+                }
+            }
+        }
+        double bound = __builtin_inf();
+        if (xlo > 0)      bound = fmin(bound, x.x - (M.grid_x0 + (double)xlo * M.grid_hx));
+        if (xhi < nx - 1) bound = fmin(bound, (M.grid_x0 + (double)(xhi + 1) * M.grid_hx) - x.x);
+        if (ylo > 0)      bound = fmin(bound, x.y - (M.grid_y0 + (double)ylo * M.grid_hy));
+        if (yhi < ny - 1) bound = fmin(bound, (M.grid_y0 + (double)(yhi + 1) * M.grid_hy) - x.y);
+        if (bound == __builtin_inf()) break;                     // the block covers the whole grid
+        bound -= M.grid_tiny;
+        if (best >= 0 && bound > 0.0 && bd < bound * bound) break;
+    }
+    return best < 0 ? 0 : best;
 }
 
 // the <= 8 faces around the nearest point: plane hit + area-sum test, first passing (:350-426)
@@ -620,42 +667,65 @@ __device__ int ct_find_simplex(const KMesh& M, double x0, double x1, int start, 
     return -1;
 }
 
-__device__ double ct_eval(const KMesh& M, int isimplex, const double* b, int which)
+// the parts of the evaluation that do not depend on which of the four interpolated quantities is
+// asked for: edge vectors, the neighbour weights g, and the 19 Bernstein products of the point
+struct CtShared {
+    int v0, v1, v2;
+    double e12x, e12y, e23x, e23y, e31x, e31y;
+    double g[3];
+    double m[19];
+};
+
+__device__ void ct_shared(const KMesh& M, int isimplex, const double* b, CtShared& G)
 {
     const int* v = M.ct_simplices + 3 * isimplex;
     const double* pts = M.ct_points;
+    G.v0 = v[0]; G.v1 = v[1]; G.v2 = v[2];
+    G.e12x = pts[2 * v[1]] - pts[2 * v[0]]; G.e12y = pts[2 * v[1] + 1] - pts[2 * v[0] + 1];
+    G.e23x = pts[2 * v[2]] - pts[2 * v[1]]; G.e23y = pts[2 * v[2] + 1] - pts[2 * v[1] + 1];
+    G.e31x = pts[2 * v[0]] - pts[2 * v[2]]; G.e31y = pts[2 * v[0] + 1] - pts[2 * v[2] + 1];
+    for (int k = 0; k < 3; k++) {
+        const int itri = M.ct_neighbors[3 * isimplex + k];
+        if (itri == -1) { G.g[k] = -1. / 2; continue; }
+        const int* w = M.ct_simplices + 3 * itri;
+        double c[3];
+        const double y0 = (pts[2 * w[0]] + pts[2 * w[1]] + pts[2 * w[2]]) / 3;
+        const double y1 = (pts[2 * w[0] + 1] + pts[2 * w[1] + 1] + pts[2 * w[2] + 1]) / 3;
+        ct_bary(M.ct_transform + 6 * isimplex, y0, y1, c);
+        if (k == 0)      G.g[k] = (2 * c[2] + c[1] - 1) / (2 - 3 * c[2] - 3 * c[1]);
+        else if (k == 1) G.g[k] = (2 * c[0] + c[2] - 1) / (2 - 3 * c[0] - 3 * c[2]);
+        else             G.g[k] = (2 * c[1] + c[0] - 1) / (2 - 3 * c[1] - 3 * c[0]);
+    }
+    double minval = b[0];
+    for (int k = 0; k < 3; k++) if (b[k] < minval) minval = b[k];
+    const double b1 = b[0] - minval, b2 = b[1] - minval, b3 = b[2] - minval, b4 = 3 * minval;
+    double* m = G.m;
+    m[0] = pow(b1, 3);            m[1] = 3 * pow(b1, 2) * b2;   m[2] = 3 * pow(b1, 2) * b3;  m[3] = 3 * pow(b1, 2) * b4;
+    m[4] = 3 * b1 * pow(b2, 2);   m[5] = 6 * b1 * b2 * b4;      m[6] = 3 * b1 * pow(b3, 2);  m[7] = 6 * b1 * b3 * b4;
+    m[8] = 3 * b1 * pow(b4, 2);   m[9] = pow(b2, 3);            m[10] = 3 * pow(b2, 2) * b3; m[11] = 3 * pow(b2, 2) * b4;
+    m[12] = 3 * b2 * pow(b3, 2);  m[13] = 6 * b2 * b3 * b4;     m[14] = 3 * b2 * pow(b4, 2); m[15] = pow(b3, 3);
+    m[16] = 3 * pow(b3, 2) * b4;  m[17] = 3 * b3 * pow(b4, 2);  m[18] = pow(b4, 3);
+}
+
+__device__ double ct_eval(const KMesh& M, const CtShared& G, int which)
+{
     const double* val = M.ct_values + (size_t)which * M.n_points;
     const double* grd = M.ct_grad + (size_t)which * M.n_points * 2;
-    const double e12x = pts[2 * v[1]] - pts[2 * v[0]], e12y = pts[2 * v[1] + 1] - pts[2 * v[0] + 1];
-    const double e23x = pts[2 * v[2]] - pts[2 * v[1]], e23y = pts[2 * v[2] + 1] - pts[2 * v[1] + 1];
-    const double e31x = pts[2 * v[0]] - pts[2 * v[2]], e31y = pts[2 * v[0] + 1] - pts[2 * v[2] + 1];
-    const double f1 = val[v[0]], f2 = val[v[1]], f3 = val[v[2]];
-    const double* d1 = grd + 2 * v[0]; const double* d2 = grd + 2 * v[1]; const double* d3 = grd + 2 * v[2];
-    const double df12 = +(d1[0] * e12x + d1[1] * e12y);
-    const double df21 = -(d2[0] * e12x + d2[1] * e12y);
-    const double df23 = +(d2[0] * e23x + d2[1] * e23y);
-    const double df32 = -(d3[0] * e23x + d3[1] * e23y);
-    const double df31 = +(d3[0] * e31x + d3[1] * e31y);
-    const double df13 = -(d1[0] * e31x + d1[1] * e31y);
+    const double f1 = val[G.v0], f2 = val[G.v1], f3 = val[G.v2];
+    const double* d1 = grd + 2 * G.v0; const double* d2 = grd + 2 * G.v1; const double* d3 = grd + 2 * G.v2;
+    const double df12 = +(d1[0] * G.e12x + d1[1] * G.e12y);
+    const double df21 = -(d2[0] * G.e12x + d2[1] * G.e12y);
+    const double df23 = +(d2[0] * G.e23x + d2[1] * G.e23y);
+    const double df32 = -(d3[0] * G.e23x + d3[1] * G.e23y);
+    const double df31 = +(d3[0] * G.e31x + d3[1] * G.e31y);
+    const double df13 = -(d1[0] * G.e31x + d1[1] * G.e31y);
     const double c3000 = f1, c2100 = (df12 + 3 * c3000) / 3, c2010 = (df13 + 3 * c3000) / 3;
     const double c0300 = f2, c1200 = (df21 + 3 * c0300) / 3, c0210 = (df23 + 3 * c0300) / 3;
     const double c0030 = f3, c1020 = (df31 + 3 * c0030) / 3, c0120 = (df32 + 3 * c0030) / 3;
     const double c2001 = (c2100 + c2010 + c3000) / 3;
     const double c0201 = (c1200 + c0300 + c0210) / 3;
     const double c0021 = (c1020 + c0120 + c0030) / 3;
-    double g[3];
-    for (int k = 0; k < 3; k++) {
-        const int itri = M.ct_neighbors[3 * isimplex + k];
-        if (itri == -1) { g[k] = -1. / 2; continue; }
-        const int* w = M.ct_simplices + 3 * itri;
-        double c[3];
-        const double y0 = (pts[2 * w[0]] + pts[2 * w[1]] + pts[2 * w[2]]) / 3;
-        const double y1 = (pts[2 * w[0] + 1] + pts[2 * w[1] + 1] + pts[2 * w[2] + 1]) / 3;
-        ct_bary(M.ct_transform + 6 * isimplex, y0, y1, c);
-        if (k == 0)      g[k] = (2 * c[2] + c[1] - 1) / (2 - 3 * c[2] - 3 * c[1]);
-        else if (k == 1) g[k] = (2 * c[0] + c[2] - 1) / (2 - 3 * c[0] - 3 * c[2]);
-        else             g[k] = (2 * c[1] + c[0] - 1) / (2 - 3 * c[1] - 3 * c[0]);
-    }
+    const double* g = G.g;
     const double c0111 = (g[0] * (-c0300 + 3 * c0210 - 3 * c0120 + c0030) + (-c0300 + 2 * c0210 - c0120 + c0021 + c0201)) / 2;
     const double c1011 = (g[1] * (-c0030 + 3 * c1020 - 3 * c2010 + c3000) + (-c0030 + 2 * c1020 - c2010 + c2001 + c0021)) / 2;
     const double c1101 = (g[2] * (-c3000 + 3 * c2100 - 3 * c1200 + c0300) + (-c3000 + 2 * c2100 - c1200 + c2001 + c0201)) / 2;
@@ -663,45 +733,77 @@ __device__ double ct_eval(const KMesh& M, int isimplex, const double* b, int whi
     const double c0102 = (c1101 + c0111 + c0201) / 3;
     const double c0012 = (c1011 + c0111 + c0021) / 3;
     const double c0003 = (c1002 + c0102 + c0012) / 3;
-    double minval = b[0];
-    for (int k = 0; k < 3; k++) if (b[k] < minval) minval = b[k];
-    const double b1 = b[0] - minval, b2 = b[1] - minval, b3 = b[2] - minval, b4 = 3 * minval;
-    return (pow(b1, 3) * c3000 + 3 * pow(b1, 2) * b2 * c2100 + 3 * pow(b1, 2) * b3 * c2010 + 3 * pow(b1, 2) * b4 * c2001 +
-            3 * b1 * pow(b2, 2) * c1200 + 6 * b1 * b2 * b4 * c1101 + 3 * b1 * pow(b3, 2) * c1020 + 6 * b1 * b3 * b4 * c1011 +
-            3 * b1 * pow(b4, 2) * c1002 + pow(b2, 3) * c0300 + 3 * pow(b2, 2) * b3 * c0210 + 3 * pow(b2, 2) * b4 * c0201 +
-            3 * b2 * pow(b3, 2) * c0120 + 6 * b2 * b3 * b4 * c0111 + 3 * b2 * pow(b4, 2) * c0102 + pow(b3, 3) * c0030 +
-            3 * pow(b3, 2) * b4 * c0021 + 3 * b3 * pow(b4, 2) * c0012 + pow(b4, 3) * c0003);
+    const double* m = G.m;
+    return (m[0] * c3000 + m[1] * c2100 + m[2] * c2010 + m[3] * c2001 +
+            m[4] * c1200 + m[5] * c1101 + m[6] * c1020 + m[7] * c1011 +
+            m[8] * c1002 + m[9] * c0300 + m[10] * c0210 + m[11] * c0201 +
+            m[12] * c0120 + m[13] * c0111 + m[14] * c0102 + m[15] * c0030 +
+            m[16] * c0021 + m[17] * c0012 + m[18] * c0003);
 }
 
-// ShapeMesh.intersect (:135-170): intersection point and surface normal together
-__device__ bool mesh_intersect(const KMesh& M, const Ray& ray, V3& X, V3& nrm)
+// ShapeMesh.intersect (:135-170), position part.  `aux` identifies what the normal is taken
+// from afterwards: the hit face (flat) or the Clough-Tocher simplex (interpolated; -1: outside).
+struct MeshHit { double x, y, z; int aux; int hit; };
+
+__device__ __noinline__ MeshHit mesh_hit(const KMesh* Mp, double ox, double oy, double oz, double dx, double dy, double dz)
 {
+    const KMesh& M = *Mp;
+    Ray ray;
+    ray.o.x = ox; ray.o.y = oy; ray.o.z = oz; ray.d.x = dx; ray.d.y = dy; ray.d.z = dz; ray.wl = 0.0;
+    MeshHit h;
+    h.x = h.y = h.z = 0.0; h.aux = 0; h.hit = 0;
+    V3 X;
+    X.x = X.y = X.z = 0.0;
     int face = 0, idx = -1;
     if (M.n_coarse_faces > 0) {
         V3 xc;
-        if (!mesh_intersect_1(M.c_p0, M.c_edge1, M.c_edge2, M.n_coarse_faces, ray, xc, face)) return false;
+        if (!mesh_intersect_1(M.c_p0, M.c_edge1, M.c_edge2, M.n_coarse_faces, ray, xc, face)) return h;
         idx = mesh_nearest(M, xc);
-        if (!mesh_intersect_2(M, idx, ray, X, face)) return false;
+        if (!mesh_intersect_2(M, idx, ray, X, face)) return h;
     } else {
-        if (!mesh_intersect_1(M.p0, M.edge1, M.edge2, M.n_faces, ray, X, face)) return false;
+        if (!mesh_intersect_1(M.p0, M.edge1, M.edge2, M.n_faces, ray, X, face)) return h;
     }
+    h.hit = 1;
+    h.aux = face;
     if (M.interpolate) {
         double c[3];
         int start = (idx >= 0) ? M.ct_vertex_simplex[idx] : 0;
         if (start < 0) start = 0;
         const int sx = ct_find_simplex(M, X.x, X.y, start, c);
-        V3 nn;
-        if (sx < 0) { X.z = __builtin_nan(""); nn.x = nn.y = nn.z = __builtin_nan(""); }
+        h.aux = sx;
+        if (sx < 0) X.z = __builtin_nan("");
         else {
-            X.z = ct_eval(M, sx, c, 0);
-            nn.x = ct_eval(M, sx, c, 1); nn.y = ct_eval(M, sx, c, 2); nn.z = ct_eval(M, sx, c, 3);
+            CtShared G;
+            ct_shared(M, sx, c, G);
+            X.z = ct_eval(M, G, 0);
+        }
+    }
+    h.x = X.x; h.y = X.y; h.z = X.z;
+    return h;
+}
+
+// ShapeMesh.intersect, normal part: the hit face's normal (:428-432), or the interpolated normal
+// re-normalised as (1/|n|) n (:182-193); the barycentric coordinates are those of the walk's last step
+__device__ __noinline__ V3 mesh_normal(const KMesh* Mp, double x, double y, int aux)
+{
+    const KMesh& M = *Mp;
+    V3 nrm;
+    if (M.interpolate) {
+        V3 nn;
+        if (aux < 0) { nn.x = nn.y = nn.z = __builtin_nan(""); }
+        else {
+            double c[3];
+            ct_bary(M.ct_transform + 6 * aux, x, y, c);
+            CtShared G;
+            ct_shared(M, aux, c, G);
+            nn.x = ct_eval(M, G, 1); nn.y = ct_eval(M, G, 2); nn.z = ct_eval(M, G, 3);
         }
         const double inv = 1.0 / norm3(nn);
         nrm.x = inv * nn.x; nrm.y = inv * nn.y; nrm.z = inv * nn.z;
     } else {
-        nrm = ld3(M.faces_normal + 3 * face);
+        nrm = ld3(M.faces_normal + 3 * aux);
     }
-    return true;
+    return nrm;
 }
 
 // tools/xicsrt_aperture.py:108-204
@@ -1068,13 +1170,16 @@ struct KArgs {
 #define XRT_WAVES_PER_EU 4
 #endif
 
-// HIST: write the per-element history.  FULL: every source/shape/aperture
-// feature; !FULL: the lean variant (isotropic cone, shared cone axis, constant
-// or uniform wavelength, plane/sphere, no apertures) with lower register use.
-template <bool HIST, bool FULL>
-__global__ __launch_bounds__(XRT_TILE, XRT_WAVES_PER_EU)
+// HIST: write the per-element history.  VARIANT 0: the lean variant (isotropic
+// cone, shared cone axis, constant or uniform wavelength, plane/sphere, no
+// apertures) with lower register use; 1: every source / analytic shape /
+// aperture feature; 2: 1 + optics traced in their local frame and mesh optics.
+template <bool HIST, int VARIANT>
+__global__ __launch_bounds__(XRT_TILE, (VARIANT == 2 ? 2 : XRT_WAVES_PER_EU))
 void xrt_trace_kernel(const KScene sc, const KArgs args)
 {
+    constexpr bool FULL = VARIANT >= 1;
+    constexpr bool EXT = VARIANT == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     // One circular structure-of-arrays buffer of XRT_QCAP ray records serves as
     //  (a) the FIFO queue of rays waiting for the Bragg test (filled tile by tile in ray
@@ -1082,7 +1187,8 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
     //  (b) scratch for the stable compactions between the other elements (its free part).
     double*   qbuf   = reinterpret_cast<double*>(lds_raw);                             // [7][XRT_QCAP]
     uint32_t* qid    = reinterpret_cast<uint32_t*>(qbuf + XRT_TILE_COMP * XRT_QCAP);   // [XRT_QCAP]
-    uint32_t* rings  = qid + XRT_QCAP;                                                 // [nh+1][1024]
+    uint32_t* qaux   = qid + XRT_QCAP;                                                 // [XRT_QCAP] (EXT only)
+    uint32_t* rings  = qaux + (EXT ? XRT_QCAP : 0u);                                   // [nh+1][1024]
     const int tid = threadIdx.x;
     const KSource& S = sc.src;
     const int64_t N = S.n_rays;
@@ -1100,13 +1206,13 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
     for (int e = 0; e < sc.n_optics; e++)
         if (sc.opt[e].interact == XRT_INTERACT_CRYSTAL && (sc.opt[e].flags & XRT_F_CHECK_BRAGG)) be = e;
 
-    auto q_store = [&](uint32_t i, const V3& o, const V3& d, double wl, uint32_t id) {
+    auto q_store = [&](uint32_t i, const V3& o, const V3& d, double wl, uint32_t id) __attribute__((always_inline)) {
         qbuf[0 * XRT_QCAP + i] = o.x; qbuf[1 * XRT_QCAP + i] = o.y; qbuf[2 * XRT_QCAP + i] = o.z;
         qbuf[3 * XRT_QCAP + i] = d.x; qbuf[4 * XRT_QCAP + i] = d.y; qbuf[5 * XRT_QCAP + i] = d.z;
         qbuf[6 * XRT_QCAP + i] = wl;
         qid[i] = id;
     };
-    auto q_load = [&](uint32_t i, V3& o, V3& d, double& wl, uint32_t& id) {
+    auto q_load = [&](uint32_t i, V3& o, V3& d, double& wl, uint32_t& id) __attribute__((always_inline)) {
         o.x = qbuf[0 * XRT_QCAP + i]; o.y = qbuf[1 * XRT_QCAP + i]; o.z = qbuf[2 * XRT_QCAP + i];
         d.x = qbuf[3 * XRT_QCAP + i]; d.y = qbuf[4 * XRT_QCAP + i]; d.z = qbuf[5 * XRT_QCAP + i];
         wl = qbuf[6 * XRT_QCAP + i];
@@ -1154,7 +1260,7 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
         // than 512 words ready extends its window by at most 227 words.  Steps
         // must be separated by a barrier; they are placed in front of barriers
         // the tile needs anyway.
-        auto mt_step = [&]() {
+        auto mt_step = [&]() __attribute__((always_inline)) {
             int h = 0;
 #pragma unroll
             for (int k = 0; k < 6; k++) {
@@ -1186,7 +1292,7 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
                 sgen += chunk;
             }
         };
-        auto heads_short = [&]() -> bool {
+        auto heads_short = [&]() __attribute__((always_inline)) -> bool {
             bool sh = false;
 #pragma unroll
             for (int k = 0; k < 6; k++)
@@ -1205,18 +1311,33 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
         // Bragg element, where it returns true with the candidates' state for the caller to queue.
         // `scratch`: first free record of the circular buffer, used for the compactions.
         auto plain_elements = [&](int e, bool fresh, uint32_t n_in, bool& have, bool& alive, Ray& ray, V3& X,
-                                  uint32_t& id, uint32_t scratch) -> int {
+                                  uint32_t& id, int& aux, uint32_t scratch) __attribute__((always_inline)) -> int {
             for (; e < sc.n_optics && n_in > 0; e++) {
                 const KOptic& op = sc.opt[e];
                 if (fresh) {
                     alive = false;
+                    const bool local = EXT && (op.flags & XRT_F_TRACE_LOCAL);
+                    const bool is_mesh = EXT && (op.shape == XRT_SHAPE_MESH);
                     if (have) {
-                        bool hit = intersect_point<FULL>(op, ray, X);
+                        if (local) {    // TraceObject.trace_global -> ray_to_local (optics/_TraceObject.py:146-148)
+                            ray.o = to_local(op.R, sub3(ray.o, ld3(op.origin)));
+                            ray.d = to_local(op.R, ray.d);
+                        }
+                        bool hit;
+                        if (is_mesh) {
+                            const MeshHit h = mesh_hit(op.mesh, ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z);
+                            hit = h.hit != 0; X.x = h.x; X.y = h.y; X.z = h.z; aux = h.aux;
+                        } else hit = intersect_point<FULL>(op, ray, X);
                         alive = hit && check_bounds<FULL>(op, X);
                         if (HIST && !alive) {
-                            V3 xo = X;
+                            V3 xo = X, dd = ray.d;
                             if (!hit) { xo.x = xo.y = xo.z = __builtin_nan(""); }
-                            hist_write(args.hist, args.hmask, N, e + 1, id, xo, ray.d, ray.wl, false);
+                            if (local) {
+                                xo = to_external(op.R, xo);
+                                xo.x += op.origin[0]; xo.y += op.origin[1]; xo.z += op.origin[2];
+                                dd = to_external(op.R, dd);
+                            }
+                            hist_write(args.hist, args.hmask, N, e + 1, id, xo, dd, ray.wl, false);
                         }
                     }
                     if (e == be) return e;                       // candidates for the Bragg queue
@@ -1224,11 +1345,16 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
                     if (alive) {
                         ray.o = X;
                         if (op.interact != XRT_INTERACT_NONE) {
-                            V3 nrm = surface_normal<FULL>(op, X);
+                            V3 nrm = is_mesh ? mesh_normal(op.mesh, X.x, X.y, aux) : surface_normal<FULL>(op, X);
                             double dt = dot_e(ray.d, nrm);
                             ray.d.x = ray.d.x - 2.0 * (dt * nrm.x);
                             ray.d.y = ray.d.y - 2.0 * (dt * nrm.y);
                             ray.d.z = ray.d.z - 2.0 * (dt * nrm.z);
+                        }
+                        if (local) {    // ray_to_external (optics/_TraceObject.py:152-154)
+                            ray.o = to_external(op.R, ray.o);
+                            ray.o.x += op.origin[0]; ray.o.y += op.origin[1]; ray.o.z += op.origin[2];
+                            ray.d = to_external(op.R, ray.d);
                         }
                         if (HIST) hist_write(args.hist, args.hmask, N, e + 1, id, ray.o, ray.d, ray.wl, true);
                     }
@@ -1288,19 +1414,24 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
             V3 X;
             X.x = X.y = X.z = 0.0;
             uint32_t id = (uint32_t)(i0 + tid);
+            int aux = 0;
             bool have = (uint32_t)tid < n_tile, alive = false;
             source_ray<FULL>(S, u, ray);
             if (tid == 0) cnt[0] += n_tile;
             if (HIST && have) hist_write(args.hist, args.hmask, N, 0, id, ray.o, ray.d, ray.wl, true);
 
             // elements in config order (objects/_Dispatcher.py:166-196) up to the Bragg element
-            const int stop = plain_elements(0, true, n_tile, have, alive, ray, X, id, q_wrap(qhead + qcount));
+            const int stop = plain_elements(0, true, n_tile, have, alive, ray, X, id, aux, q_wrap(qhead + qcount));
             if (stop >= 0) {
                 // queue the candidates in ray order: ordered live rank -> FIFO position
+                // (a locally traced element queues its local-frame point and direction)
                 uint32_t n_a;
                 mt_step();
                 uint32_t rank = wg_rank(alive, wave_tot, slot, tid, n_a);
-                if (alive) q_store(q_wrap(qhead + qcount + rank), X, ray.d, ray.wl, id);
+                if (alive) {
+                    q_store(q_wrap(qhead + qcount + rank), X, ray.d, ray.wl, id);
+                    if (EXT) qaux[q_wrap(qhead + qcount + rank)] = (uint32_t)aux;
+                }
                 qcount += n_a;
             }
 
@@ -1315,19 +1446,35 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
                 __syncthreads();                                  // queue records visible
                 have = (uint32_t)tid < nb;
                 alive = false;
+                const bool local = EXT && (op.flags & XRT_F_TRACE_LOCAL);
                 if (have) {
                     q_load(q_wrap(qhead + (uint32_t)tid), X, ray.d, ray.wl, id);
-                    V3 nrm = surface_normal<FULL>(op, X);
+                    V3 nrm;
+                    if (EXT && op.shape == XRT_SHAPE_MESH) nrm = mesh_normal(op.mesh, X.x, X.y, (int)qaux[q_wrap(qhead + (uint32_t)tid)]);
+                    else nrm = surface_normal<FULL>(op, X);
                     uint32_t n = spos + 2u * (uint32_t)tid;
                     double test = 0.0 + (1.0 - 0.0) * mt_double(stream[n & XRT_RMASK], stream[(n + 1u) & XRT_RMASK]);
                     alive = bragg_accept(op, ray, nrm, test, wl_shared, bragg_shared);
-                    if (HIST && !alive) hist_write(args.hist, args.hmask, N, be + 1, id, X, ray.d, ray.wl, false);
+                    if (HIST && !alive) {
+                        V3 xo = X, dd = ray.d;
+                        if (local) {
+                            xo = to_external(op.R, xo);
+                            xo.x += op.origin[0]; xo.y += op.origin[1]; xo.z += op.origin[2];
+                            dd = to_external(op.R, dd);
+                        }
+                        hist_write(args.hist, args.hmask, N, be + 1, id, xo, dd, ray.wl, false);
+                    }
                     if (alive) {
                         ray.o = X;
                         double dt = dot_e(ray.d, nrm);
                         ray.d.x = ray.d.x - 2.0 * (dt * nrm.x);
                         ray.d.y = ray.d.y - 2.0 * (dt * nrm.y);
                         ray.d.z = ray.d.z - 2.0 * (dt * nrm.z);
+                        if (local) {
+                            ray.o = to_external(op.R, ray.o);
+                            ray.o.x += op.origin[0]; ray.o.y += op.origin[1]; ray.o.z += op.origin[2];
+                            ray.d = to_external(op.R, ray.d);
+                        }
                         if (HIST) hist_write(args.hist, args.hmask, N, be + 1, id, ray.o, ray.d, ray.wl, true);
                     }
                 }
@@ -1336,7 +1483,7 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
                 const uint32_t freed = qhead;                     // these records are free again: compaction scratch
                 qhead = q_wrap(qhead + nb);
                 qcount -= nb;
-                plain_elements(be, false, nb, have, alive, ray, X, id, freed);
+                plain_elements(be, false, nb, have, alive, ray, X, id, aux, freed);
             }
         }
 
@@ -1479,8 +1626,6 @@ static bool needs_staged(const xrt_scene_t* sc)
     int n_bragg = 0;
     for (int e = 0; e < sc->n_optics; e++) {
         if (sc->optics[e].interact == XRT_INTERACT_MOSAIC) return true;     // whole-array passes per layer
-        if (sc->optics[e].flags & XRT_F_TRACE_LOCAL) return true;
-        if (sc->optics[e].shape == XRT_SHAPE_MESH) return true;
         if (sc->optics[e].interact == XRT_INTERACT_CRYSTAL && (sc->optics[e].flags & XRT_F_CHECK_BRAGG)) n_bragg++;
     }
     return n_bragg > 1;
@@ -1497,6 +1642,7 @@ static size_t mesh_bytes(const xrt_mesh_t* m)
     const size_t P = (size_t)m->n_points, F = (size_t)m->n_faces, Cn = (size_t)m->n_coarse_faces, T = (size_t)m->n_simplices;
     b += al256(P * 3 * 8) + 7 * al256(F * 3 * 8) + al256(P * 8 * 4) + al256(P * 8) + 3 * al256(Cn * 3 * 8 + 8);
     if (m->interpolate) b += 2 * al256(T * 3 * 4) + al256(T * 6 * 8) + al256(P * 2 * 8) + al256(4 * P * 8) + al256(8 * P * 8) + al256(P * 4);
+    b += al256((P + 2) * 4) + al256(P * 4) + al256(P * 24);          // bucket grid: <= P buckets
     return b;
 }
 static size_t meshes_bytes(const xrt_scene_t* sc)
@@ -1519,6 +1665,14 @@ extern "C" size_t xrt_workspace_bytes(const xrt_scene_t* sc, int32_t n_runs)
     if (!sc || n_runs < 0) return 0;
     if (n_runs < 1) n_runs = 1;
     return ws_off_staged(sc, n_runs) + staged_bytes(sc, n_runs) + meshes_bytes(sc) + 256;
+}
+
+// fused-kernel variant 2: an optic traced in its local frame, or a mesh
+static bool needs_ext(const xrt_scene_t* sc)
+{
+    for (int e = 0; e < sc->n_optics; e++)
+        if ((sc->optics[e].flags & XRT_F_TRACE_LOCAL) || sc->optics[e].shape == XRT_SHAPE_MESH) return true;
+    return false;
 }
 
 static bool needs_full(const xrt_scene_t* sc)
@@ -1602,9 +1756,9 @@ static void build_kscene(const xrt_scene_t* sc, char* ws, KScene* k)
     }
 }
 
-static size_t lds_bytes(int n_src_heads)
+static size_t lds_bytes(int n_src_heads, bool ext)
 {
-    size_t b = sizeof(double) * XRT_TILE_COMP * XRT_QCAP + sizeof(uint32_t) * XRT_QCAP;
+    size_t b = sizeof(double) * XRT_TILE_COMP * XRT_QCAP + sizeof(uint32_t) * XRT_QCAP * (ext ? 2 : 1);
     b += sizeof(uint32_t) * XRT_RING * (size_t)(n_src_heads + 1);
     b += sizeof(uint32_t) * (8 + 2 * (XRT_DEV_MAX_OPTICS + 2) + 8);
     return (b + 15) & ~(size_t)15;
@@ -1649,6 +1803,58 @@ static int upload_meshes(const xrt_scene_t* sc, char* ws, int n_runs, KScene* ks
             k.ct_grad = (const double*)put(m->ct_grad, 8 * P * 8);
             k.ct_vertex_simplex = (const int32_t*)put(m->ct_vertex_simplex, P * 4);
         }
+        if (m->n_coarse_faces > 0 && P > 0) {
+            // x-y bucket grid for the nearest-point search, about one point per bucket
+            double lo[2] = {m->points[0], m->points[1]}, hi[2] = {m->points[0], m->points[1]};
+            for (size_t i = 0; i < P; i++)
+                for (int a = 0; a < 2; a++) {
+                    const double v = m->points[3 * i + a];
+                    if (v < lo[a]) lo[a] = v;
+                    if (v > hi[a]) hi[a] = v;
+                }
+            int g = (int)floor(sqrt((double)P));
+            if (g < 1) g = 1;
+            int nx = g, ny = g;
+            while ((size_t)nx * ny > P) ny--;
+            double ext[2] = {hi[0] - lo[0], hi[1] - lo[1]};
+            if (!(ext[0] > 0.0)) { ext[0] = 1.0; nx = 1; }
+            if (!(ext[1] > 0.0)) { ext[1] = 1.0; ny = 1; }
+            bool finite = std::isfinite(ext[0]) && std::isfinite(ext[1]);
+            if (finite) {
+                k.grid_nx = nx; k.grid_ny = ny;
+                k.grid_x0 = lo[0]; k.grid_y0 = lo[1];
+                k.grid_hx = ext[0] / nx; k.grid_hy = ext[1] / ny;
+                k.grid_ihx = 1.0 / k.grid_hx; k.grid_ihy = 1.0 / k.grid_hy;
+                k.grid_tiny = 1e-9 * (k.grid_hx > k.grid_hy ? k.grid_hx : k.grid_hy);
+                static thread_local std::vector<int32_t> cstart, cidx, ccell;
+                static thread_local std::vector<double> cxyz;
+                const size_t NC = (size_t)nx * ny;
+                cstart.assign(NC + 1, 0); cidx.resize(P); ccell.resize(P); cxyz.resize(3 * P);
+                for (size_t i = 0; i < P; i++) {
+                    double fx = floor((m->points[3 * i] - k.grid_x0) * k.grid_ihx), fy = floor((m->points[3 * i + 1] - k.grid_y0) * k.grid_ihy);
+                    if (!(fx >= 0.0)) fx = 0.0;
+                    if (!(fy >= 0.0)) fy = 0.0;
+                    const int cx = fx > (double)(nx - 1) ? nx - 1 : (int)fx, cy = fy > (double)(ny - 1) ? ny - 1 : (int)fy;
+                    ccell[i] = cy * nx + cx;
+                    cstart[(size_t)ccell[i] + 1]++;
+                }
+                for (size_t c = 0; c < NC; c++) cstart[c + 1] += cstart[c];
+                std::vector<int32_t> fill(cstart.begin(), cstart.end() - 1);
+                for (size_t i = 0; i < P; i++) {                 // ascending point index inside a bucket
+                    const int32_t o = fill[ccell[i]]++;
+                    cidx[o] = (int32_t)i;
+                    for (int a = 0; a < 3; a++) cxyz[3 * (size_t)o + a] = m->points[3 * i + a];
+                }
+                // synchronous copies: the vectors are reused by the next call
+                char* d0 = p; p += al256((P + 2) * 4);
+                char* d1 = p; p += al256(P * 4);
+                char* d2 = p; p += al256(P * 24);
+                HIP_TRY(hipMemcpy(d0, cstart.data(), (NC + 1) * 4, hipMemcpyHostToDevice));
+                HIP_TRY(hipMemcpy(d1, cidx.data(), P * 4, hipMemcpyHostToDevice));
+                HIP_TRY(hipMemcpy(d2, cxyz.data(), P * 24, hipMemcpyHostToDevice));
+                k.cell_start = (const int32_t*)d0; k.cell_idx = (const int32_t*)d1; k.cell_xyz = (const double*)d2;
+            }
+        }
         HIP_TRY(hipMemcpyAsync(base, &k, sizeof(KMesh), hipMemcpyHostToDevice, stream));
         ks->opt[e].mesh = reinterpret_cast<const KMesh*>(base);
         base += mesh_bytes(m);
@@ -1672,10 +1878,10 @@ static int upload_tables(const xrt_scene_t* sc, char* ws, hipStream_t stream)
     return 0;
 }
 
-template <bool HIST, bool FULL>
+template <bool HIST, int VARIANT>
 static int launch_variant(const KScene& ks, const KArgs& a, int n_runs, size_t lds, hipStream_t stream)
 {
-    auto kern = xrt_trace_kernel<HIST, FULL>;
+    auto kern = xrt_trace_kernel<HIST, VARIANT>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int dev = 0, cus = 256, per_cu = 1;
     HIP_TRY(hipGetDevice(&dev));
@@ -1725,7 +1931,7 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
         a.streams = streams; a.heads = heads; a.n_runs = n_runs; a.n_src_heads = nh;
         a.run_counter = reinterpret_cast<uint32_t*>(ws);
         HIP_TRY(hipMemsetAsync(ws, 0, 64, stream));
-        const size_t lds = sizeof(double) * 10 * XRT_TILE + sizeof(uint32_t) * (XRT_TILE + XRT_RING + 64);
+        const size_t lds = sizeof(double) * XRT_TILE_COMP * XRT_TILE + sizeof(uint32_t) * (2 * XRT_TILE + XRT_RING + 64);
         int ti = -1;
         if (timing_on && timing_n < TIMING_MAX) {
             ti = timing_n++;
@@ -1771,10 +1977,14 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
     a.streams = streams; a.heads = heads; a.n_runs = n_runs; a.n_src_heads = nh;
     a.run_counter = reinterpret_cast<uint32_t*>(ws);
     HIP_TRY(hipMemsetAsync(ws, 0, 64, stream));
-    const size_t lds = lds_bytes(nh);
-    const bool full = needs_full(sc);
-    if (hist) return full ? launch_variant<true, true>(ks, a, n_runs, lds, stream) : launch_variant<true, false>(ks, a, n_runs, lds, stream);
-    return full ? launch_variant<false, true>(ks, a, n_runs, lds, stream) : launch_variant<false, false>(ks, a, n_runs, lds, stream);
+    const int variant = needs_ext(sc) ? 2 : (needs_full(sc) ? 1 : 0);
+    const size_t lds = lds_bytes(nh, variant == 2);
+    if (hist) {
+        if (variant == 2) return launch_variant<true, 2>(ks, a, n_runs, lds, stream);
+        return variant == 1 ? launch_variant<true, 1>(ks, a, n_runs, lds, stream) : launch_variant<true, 0>(ks, a, n_runs, lds, stream);
+    }
+    if (variant == 2) return launch_variant<false, 2>(ks, a, n_runs, lds, stream);
+    return variant == 1 ? launch_variant<false, 1>(ks, a, n_runs, lds, stream) : launch_variant<false, 0>(ks, a, n_runs, lds, stream);
 }
 
 // diagnostic: g(t) = t^J mod phi(t) as 624 words (bit j of word j/32 = g_j); host only
