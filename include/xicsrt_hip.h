@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define XRT_ABI_VERSION 9
+#define XRT_ABI_VERSION 10
 
 #define XRT_MAX_OPTICS     16
 #define XRT_MAX_APERTURES  8
@@ -98,6 +98,48 @@ typedef struct xrt_aperture {
     double  vertices[6];      /* triangle: x0,y0,x1,y1,x2,y2 with the aperture origin already added */
 } xrt_aperture_t;
 
+/* One XicsrtBundleFilterSightline (filters/_XicsrtBundleFilterSightline.py:31-56): a bundle is
+ * kept when radius >= |l_0 - zaxis (zaxis . l_0)|, l_0 = origin - bundle centre; origin and zaxis
+ * are the filter's config values as given (zaxis is NOT normalised by the reference). */
+#define XRT_MAX_BUNDLE_FILTERS 4
+typedef struct xrt_bundle_filter {
+    double origin[3];
+    double zaxis[3];
+    double radius;
+} xrt_bundle_filter_t;
+
+enum { XRT_PLASMA_BOX = 0,       /* XicsrtPlasmaGeneric / Cubic: no flux coordinate           */
+       XRT_PLASMA_TOROIDAL = 1   /* XicsrtPlasmaToroidal(+Datafile) (_XicsrtPlasmaToroidal.py:36-45) */ };
+
+/* Per-bundle plasma model.  When xrt_source_t.plasma is non-NULL every bundle's mask,
+ * emissivity, temperature and spread are evaluated from its centre, in the reference's order:
+ * bundle_filter (sightlines) -> bundle_generate (rho, profiles, isfinite(temperature)) ->
+ * create_sources (intensity, Poisson count) (sources/_XicsrtPlasmaGeneric.py:384-393).
+ * NULL: all bundles share the source-level constants (bundle_intensity, ang, wl_*). */
+typedef struct xrt_plasma {
+    int32_t geometry;          /* XRT_PLASMA_*                                               */
+    int32_t has_spread_radius; /* spread_b = arctan(spread_radius / |centre - target|) (:218-221) */
+    int32_t n_filters;
+    int32_t n_emissivity;      /* profile points of get_emissivity(rho); 0: the constant below */
+    int32_t n_temperature;     /* profile points of get_temperature(rho); 0: constant (then the
+                                * source-level wavelength fields already describe every bundle) */
+    int32_t pad;
+    double  torus_origin[3];
+    double  major_radius, minor_radius;
+    double  emissivity;        /* get_emissivity() constant                                  */
+    double  emissivity_scale, temperature_scale;
+    const double* emissivity_rho;   /* HOST pointers, n_emissivity / n_temperature doubles each; */
+    const double* emissivity_val;   /* np.interp(rho, x, y, left=0, right=0)                     */
+    const double* temperature_rho;  /* (_XicsrtPlasmaToroidalDatafile.py:31-45)                  */
+    const double* temperature_val;
+    double  spread_radius;
+    double  solid_angle;       /* constant-spread case: 4 pi sin^2(spread/2) (xicsrt_spread.py:127) */
+    double  time_resolution, bundle_volume, four_pi, volume_ratio;  /* intensity factors (:301-319),
+                                * volume_ratio = volume / (bundle_count * bundle_volume)      */
+    double  mass_number, amu_kg, c_squared, ev_J;   /* per-bundle Doppler width, c_squared = c**2 (_XicsrtSourceGeneric.py:363-365) */
+    xrt_bundle_filter_t filters[XRT_MAX_BUNDLE_FILTERS];
+} xrt_plasma_t;
+
 typedef struct xrt_source {
     int32_t kind;             /* XRT_SRC_*      */
     int32_t spatial_dist;     /* XRT_SPATIAL_*  */
@@ -136,6 +178,7 @@ typedef struct xrt_source {
     double  bundle_intensity; /* expected rays per bundle     (:301-319)                    */
     int32_t use_poisson;      /* np.random.poisson(intensity) per bundle, else int(intensity) */
     int32_t pad_plasma;
+    const xrt_plasma_t* plasma;   /* HOST pointer or NULL: per-bundle model, see xrt_plasma_t   */
 } xrt_source_t;
 
 /* A triangulated-mesh surface (optics/_ShapeMesh.py:198-261 _mesh_precalc output), all HOST

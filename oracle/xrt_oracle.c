@@ -443,6 +443,71 @@ static void generate_block(const xrt_source_t* s, const double* origin3, mt_t* m
     for (int64_t i = 0; i < n; i++) { r->wt[i] = 1.0; r->mask[i] = 1; }
 }
 
+/* np.interp(x, xp, fp, left=0.0, right=0.0) (sources/_XicsrtPlasmaToroidalDatafile.py:34,43) */
+static double np_interp_zero(double x, const double* xp, const double* fp, int n)
+{
+    if (x != x) return x;
+    if (x < xp[0] || x > xp[n - 1]) return 0.0;
+    return np_interp(x, xp, fp, n);
+}
+
+/* What the reference's bundle pipeline assigns to the bundle centred at c (external frame):
+ * bundle_filter (filters/_XicsrtBundleFilterSightline.py:31-56), bundle_generate
+ * (sources/_XicsrtPlasmaToroidal.py:47-78 with tools/xicsrt_math.py:211-244), setup_bundle_spread
+ * and the intensity of create_sources (sources/_XicsrtPlasmaGeneric.py:206-231, :301-319).
+ * Fills `sb` (the bundle's focused source) and *lam; returns 0 when the bundle is masked out. */
+static int bundle_eval(const xrt_source_t* s, const double* c, xrt_source_t* sb, double* lam)
+{
+    const xrt_plasma_t* P = s->plasma;
+    *sb = *s;
+    for (int f = 0; f < P->n_filters; f++) {
+        const xrt_bundle_filter_t* F = &P->filters[f];
+        double l0[3], l2[3];
+        for (int k = 0; k < 3; k++) l0[k] = F->origin[k] - c[k];
+        const double proj = dot_e(F->zaxis, l0);                       /* einsum('j,ij->i') */
+        for (int k = 0; k < 3; k++) l2[k] = l0[k] - F->zaxis[k] * proj;
+        const double distance = sqrt(dot_e(l2, l2));                    /* einsum('ij,ij->i') */
+        if (!(F->radius >= distance)) return 0;
+    }
+    double emis = P->emissivity * P->emissivity_scale;
+    if (P->geometry == XRT_PLASMA_TOROIDAL) {
+        const double px = c[0] - P->torus_origin[0], py = c[1] - P->torus_origin[1], pz = c[2] - P->torus_origin[2];
+        const double d = sqrt(fma(py, py, px * px)) - P->major_radius;  /* norm of a 1-D pair: BLAS ddot */
+        const double r0 = sqrt(pz * pz + d * d);                        /* np.power(.,2) is x*x */
+        volatile double two = 2.0;
+        double flx = pow(r0, two);                                      /* numpy scalar ** 2 calls libm pow */
+        flx /= P->minor_radius;
+        const double rho = sqrt(flx);
+        if (P->n_temperature > 0) {
+            const double temp = np_interp_zero(rho, P->temperature_rho, P->temperature_val, P->n_temperature) * P->temperature_scale;
+            if (!isfinite(temp)) return 0;
+            /* the bundle's wavelength case (_XicsrtSourceGeneric.py:321-367) with linewidth == 0 */
+            if (s->wavelength_dist == XRT_WL_NORMAL || s->wavelength_dist == XRT_WL_CONST) {
+                if (temp == 0.0) sb->wavelength_dist = XRT_WL_CONST;
+                else {
+                    sb->wavelength_dist = XRT_WL_NORMAL;
+                    sb->wl_a = sqrt(temp / P->mass_number / P->amu_kg / P->c_squared * P->ev_J) * s->wavelength;
+                }
+            }
+        }
+        if (P->n_emissivity > 0)
+            emis = np_interp_zero(rho, P->emissivity_rho, P->emissivity_val, P->n_emissivity) * P->emissivity_scale;
+    }
+    double solid_angle = P->solid_angle;
+    if (P->has_spread_radius) {
+        double v[3] = {c[0] - s->axis[0], c[1] - s->axis[1], c[2] - s->axis[2]};
+        const double dist = norm3(v);
+        const double spread = atan(P->spread_radius / dist);
+        volatile double two = 2.0;
+        solid_angle = P->four_pi * pow(sin(spread / 2), two);
+        sb->ang[0] = cos(spread);
+    }
+    double intensity = emis * P->time_resolution * P->bundle_volume * solid_angle / P->four_pi;
+    intensity *= P->volume_ratio;
+    *lam = intensity;
+    return 1;
+}
+
 /* sources/_XicsrtSourceGeneric.py:198 for the plain sources; for XRT_SRC_PLASMA
  * XicsrtPlasmaGeneric.generate_rays (sources/_XicsrtPlasmaGeneric.py:384-393):
  * setup_bundles (:176-204), then one focused source per bundle in order (:286-345) whose
@@ -466,10 +531,20 @@ static int64_t generate_rays(const xrt_source_t* s, mt_t* mt, rays_t* r)
         to_external(s->orientation, v, c);                 /* point_to_external (:199) */
         for (int k = 0; k < 3; k++) c[k] = c[k] + s->origin[k];
         int64_t nb;
-        if (s->use_poisson) nb = mt_poisson(mt, s->bundle_intensity);
-        else nb = (int64_t)s->bundle_intensity;
+        xrt_source_t sb_store;
+        const xrt_source_t* sb = s;
+        double lam = s->bundle_intensity;
+        if (s->plasma) {
+            if (!bundle_eval(s, c, &sb_store, &lam)) continue;      /* masked bundles draw nothing (:288-289) */
+            sb = &sb_store;
+        }
+        if (s->use_poisson) nb = mt_poisson(mt, lam);
+        else {
+            if (lam < 1) { free(off); return -2; }                  /* ValueError (_XicsrtSourceGeneric.py:193-194) */
+            nb = (int64_t)lam;
+        }
         if (total + nb > r->n) { free(off); return -1; }
-        generate_block(s, c, mt, r, total, nb);
+        generate_block(sb, c, mt, r, total, nb);
         total += nb;
     }
     free(off);

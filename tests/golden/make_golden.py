@@ -298,6 +298,44 @@ def build_cases():
     add('F_plasma_trace', 'trace', cfg_three(0, sph, source=p, history=True, seed=61))
     add('F_plasma_counts', 'counts', cfg_three(0, sph, source=dict(p, emissivity=2e15 / 5),
                                                seed=61, runs=2))
+    # --- per-bundle plasma models: toroidal flux geometry, profile files, spread_radius,
+    #     sightline bundle filter.  Profile files are data fixtures.
+    ddir = os.path.join(HERE, 'data')
+    os.makedirs(ddir, exist_ok=True)
+    np.savetxt(os.path.join(ddir, 'emissivity_profile.txt'),
+               np.array([[0.0, 4e13], [0.15, 3.1e13], [0.3, 1.7e13], [0.45, 0.6e13], [0.55, 0.0]]))
+    np.savetxt(os.path.join(ddir, 'temperature_profile.txt'),
+               np.array([[0.0, 2500.0], [0.2, 1800.0], [0.4, 700.0], [0.5, 0.0], [0.6, 0.0]]))
+    box = dict(p, xsize=0.3, ysize=0.3, zsize=0.16, bundle_count=150, bundle_volume=1e-6,
+               spread=float(np.radians(1.5)))
+    tor = dict(box, class_name='XicsrtPlasmaToroidal', major_radius=0.08, minor_radius=0.05,
+               torus_origin=[0.01, -0.02, 0.0], emissivity=1.2e13, emissivity_scale=0.5, temperature_scale=2.0,
+               velocity=[1.0e4, 0.0, 2.0e4], velocity_scale=1.5)
+    add('F_toroidal_trace', 'trace', cfg_three(0, sph, source=tor, history=True, seed=62))
+    add('F_toroidal_nopoisson_trace', 'trace', cfg_three(0, sph, source=dict(tor, use_poisson=False, emissivity=2e13),
+                                                         history=True, seed=63))
+    dat = dict(box, class_name='XicsrtPlasmaToroidalDatafile', major_radius=0.08, minor_radius=0.05,
+               emissivity_file='tests/golden/data/emissivity_profile.txt',
+               temperature_file='tests/golden/data/temperature_profile.txt',
+               emissivity_scale=0.45, temperature_scale=1.0)
+    del dat['emissivity'], dat['temperature']
+    add('F_datafile_trace', 'trace', cfg_three(0, sph, source=dat, history=True, seed=64))
+    flt = {'sight': {'class_name': 'XicsrtBundleFilterSightline', 'origin': [0.0, 0.0, 0.80374151],
+                     'zaxis': [0.05, -0.02, -1.0], 'radius': 0.06}}
+    cfg = cfg_three(0, sph, source=dict(dat, filters=['sight']), history=True, seed=65)
+    cfg['filters'] = flt
+    add('F_datafile_filter_trace', 'trace', cfg)
+    cfg = cfg_three(0, sph, source=dict(dat, filters=['sight'], spread=None, spread_radius=0.03), seed=66, runs=2, iters=2)
+    cfg['filters'] = flt
+    add('F_datafile_filter_counts', 'counts', cfg)
+    add('F_spread_radius_trace', 'trace', cfg_three(0, sph, source=dict(box, spread=None, spread_radius=0.02,
+                                                                       emissivity=6e12), history=True, seed=67))
+    cfg = cfg_three(0, sph, source=dict(box, filters=['sight'], emissivity=2e13), history=True, seed=68)
+    cfg['filters'] = flt
+    add('F_cubic_filter_trace', 'trace', cfg)
+    add('F_generic_plasma_trace', 'trace', cfg_three(0, sph, source=dict(box, class_name='XicsrtPlasmaGeneric',
+                                                                        time_resolution=3e9), history=True, seed=69))
+
     # --- mesh set-up tables of the three generators (host-side parity) -----------
     for cls, extra in [('XicsrtOpticMeshToroidalCrystal', {'radius_major': 1.0, 'radius_minor': 0.2, 'mesh_size': [9, 7]}),
                        ('XicsrtOpticMeshSphericalCrystal', {'radius': 1.3, 'mesh_size': [8, 6]}),
@@ -341,9 +379,20 @@ def _jsonable(obj):
     return obj
 
 
+def _ref_cfg(cfg):
+    """Deep copy for the reference: its sightline filter indexes config lists as ndarrays."""
+    cfg = copy.deepcopy(cfg)
+    for f in cfg.get('filters', {}).values():
+        for k, v in f.items():
+            if isinstance(v, list):
+                f[k] = np.array(v, dtype=np.float64)
+    os.chdir(os.path.dirname(os.path.dirname(HERE)))      # relative profile-file names resolve from the repo root
+    return cfg
+
+
 def run_trace(cfg):
     """One iteration via the reference's internals, rays kept in original order."""
-    cfg = copy.deepcopy(cfg)
+    cfg = _ref_cfg(cfg)
     config = xicsrt_config.config_to_numpy(cfg)
     config = xicsrt_config.get_config(config)
     np.random.seed(config['general']['random_seed'])
@@ -375,7 +424,7 @@ def run_trace(cfg):
 
 
 def run_counts(cfg):
-    cfg = copy.deepcopy(cfg)
+    cfg = _ref_cfg(cfg)
     res = xicsrt.raytrace(cfg)
     out = {}
     names = list(res['total']['meta'].keys())

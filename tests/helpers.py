@@ -63,6 +63,12 @@ def golden_names(kind=None):
 def load_golden(name):
     d = np.load(os.path.join(GOLDEN, name + '.npz'))
     cfg = json.loads(str(d['config_json']))
+    # data fixtures (profile files) are named relative to the repo root
+    for section in ('sources', 'optics'):
+        for sub in cfg.get(section, {}).values():
+            for k, v in sub.items():
+                if k.endswith('_file') and isinstance(v, str) and not os.path.isabs(v):
+                    sub[k] = os.path.join(ROOT, v)
     return cfg, d
 
 

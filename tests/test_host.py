@@ -159,8 +159,13 @@ def test_unsupported_scenes_fail_loudly():
     cfg['optics']['crystal']['class_name'] = 'XicsrtOpticMeshMosaicCrystal'
     with pytest.raises(NotImplementedError):
         helpers.build(cfg)
-    cfg, gold = helpers.load_golden('F_plasma_trace')
-    cfg['sources']['source'].update(spread=None, spread_radius=0.05)
+    cfg, gold = helpers.load_golden('F_datafile_trace')
+    cfg['sources']['source'].update(linewidth=1e13)         # one Voigt table per bundle would be needed
+    with pytest.raises(NotImplementedError):
+        helpers.build(cfg)
+    cfg, gold = helpers.load_golden('C_sphere_trace')       # ray filters on a plain source
+    cfg['filters'] = {'sight': {'class_name': 'XicsrtBundleFilterSightline', 'radius': 0.1}}
+    cfg['sources']['source']['filters'] = ['sight']
     with pytest.raises(NotImplementedError):
         helpers.build(cfg)
 
@@ -171,7 +176,8 @@ def test_supported_scenes_validate():
                  'P_aperture2_trace', 'W_voigt_trace', 'S_focused_trace', 'G_flat_xy_trace',
                  'W_normal_trace', 'S_gaussian_spatial_trace', 'G_isotropic_xy_trace', 'Q_four_trace',
                  'P_local_trace', 'M_spherical_mosaic_cutoff_trace', 'F_plasma_trace', 'D_ToroidalCrystal_trace',
-                 'E_mesh_flat_trace', 'E_mesh_interp_trace', 'E_mesh_sphere_trace', 'E_mesh_cylinder_trace'):
+                 'E_mesh_flat_trace', 'E_mesh_interp_trace', 'E_mesh_sphere_trace', 'E_mesh_cylinder_trace',
+                 'F_toroidal_trace', 'F_datafile_filter_trace', 'F_spread_radius_trace', 'F_generic_plasma_trace'):
         cfg, gold = helpers.load_golden(name)
         config, elements, flat = helpers.build(cfg)
         assert L.xrt_scene_check(flat.byref()) == 0, (name, L.xrt_last_error())

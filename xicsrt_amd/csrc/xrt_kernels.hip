@@ -52,6 +52,17 @@
 // kernel-argument scene (passed by value: uniform, read through scalar loads)
 // --------------------------------------------------------------------------
 
+struct KPlasma {             // device copy of xrt_plasma_t (table pointers are device pointers)
+    int32_t geometry, has_spread_radius, n_filters, n_emissivity, n_temperature, pad;
+    double  torus_origin[3], major_radius, minor_radius;
+    double  emissivity, emissivity_scale, temperature_scale;
+    const double *emissivity_rho, *emissivity_val, *temperature_rho, *temperature_val;
+    double  spread_radius, solid_angle;
+    double  time_resolution, bundle_volume, four_pi, volume_ratio;
+    double  mass_number, amu_kg, c_squared, ev_J;
+    xrt_bundle_filter_t filters[XRT_MAX_BUNDLE_FILTERS];
+};
+
 struct KSource {
     int32_t kind, angular_dist, wavelength_dist, has_velocity;
     int64_t n_rays;
@@ -76,6 +87,7 @@ struct KSource {
     double  bundle_intensity;
     double  pois[7];            // sqrt(lam), log(lam), b, a, invalpha, vr, exp(-lam) (numpy's own libm expressions)
     int32_t use_poisson, pad2;
+    const KPlasma* plasma;      // device; per-bundle model or null
 };
 
 struct KMesh {               // device pointers, see xrt_mesh_t
@@ -1546,6 +1558,19 @@ extern "C" int xrt_device_count(int* count)
 extern "C" int xrt_scene_check(const xrt_scene_t* sc)
 {
     if (!sc) return fail(-1, "%s", "scene is NULL");
+    if (sc->source.plasma) {
+        const xrt_plasma_t* P = sc->source.plasma;
+        if (sc->source.kind != XRT_SRC_PLASMA) return fail(-2, "%s", "per-bundle plasma model on a non-plasma source");
+        if (P->n_filters < 0 || P->n_filters > XRT_MAX_BUNDLE_FILTERS) return fail(-2, "%s", "bad bundle filter count");
+        if (P->geometry != XRT_PLASMA_BOX && P->geometry != XRT_PLASMA_TOROIDAL) return fail(-3, "%s", "plasma geometry is not implemented on the device path");
+        if ((P->n_emissivity > 0 && (!P->emissivity_rho || !P->emissivity_val)) ||
+            (P->n_temperature > 0 && (!P->temperature_rho || !P->temperature_val)))
+            return fail(-2, "%s", "plasma profile tables missing");
+        if ((P->n_emissivity > 0 || P->n_temperature > 0) && P->geometry != XRT_PLASMA_TOROIDAL)
+            return fail(-2, "%s", "plasma profiles need a flux geometry");
+        if (P->n_temperature > 0 && sc->source.wavelength_dist == XRT_WL_VOIGT)
+            return fail(-3, "%s", "a temperature profile with a natural linewidth is not implemented on the device path");
+    }
     if (sc->n_optics < 0 || sc->n_optics > XRT_DEV_MAX_OPTICS)
         return fail(-2, "%s", "device path supports at most 8 optics");
     const xrt_source_t& s = sc->source;
@@ -1652,19 +1677,28 @@ static size_t meshes_bytes(const xrt_scene_t* sc)
     return b;
 }
 
+// device copy of the per-bundle plasma model: header + the two profile tables
+static size_t plasma_bytes(const xrt_scene_t* sc)
+{
+    const xrt_plasma_t* P = sc->source.plasma;
+    if (!P) return 0;
+    return al256(sizeof(KPlasma)) + 2 * al256(sizeof(double) * (size_t)(P->n_emissivity > 0 ? P->n_emissivity : 1))
+                                  + 2 * al256(sizeof(double) * (size_t)(P->n_temperature > 0 ? P->n_temperature : 1));
+}
+
 static size_t staged_bytes(const xrt_scene_t* sc, int n_runs)
 {
     if (!needs_staged(sc)) return 0;
     const size_t n = (size_t)(sc->source.intensity > 0 ? sc->source.intensity : 1);
     const size_t nb = (size_t)(sc->source.bundle_count > 0 ? sc->source.bundle_count : 0);
-    return al256((size_t)staged_slots(n_runs) * (n * (XRT_ST_ARRAYS * sizeof(double) + sizeof(uint32_t)) + nb * 3 * sizeof(double)) + 256);
+    return al256((size_t)staged_slots(n_runs) * (n * (XRT_ST_ARRAYS * sizeof(double) + sizeof(uint32_t)) + nb * XRT_ST_BUNDLE_ROWS * sizeof(double)) + 256);
 }
 
 extern "C" size_t xrt_workspace_bytes(const xrt_scene_t* sc, int32_t n_runs)
 {
     if (!sc || n_runs < 0) return 0;
     if (n_runs < 1) n_runs = 1;
-    return ws_off_staged(sc, n_runs) + staged_bytes(sc, n_runs) + meshes_bytes(sc) + 256;
+    return ws_off_staged(sc, n_runs) + staged_bytes(sc, n_runs) + meshes_bytes(sc) + plasma_bytes(sc) + 256;
 }
 
 // fused-kernel variant 2: an optic traced in its local frame, or a mesh
@@ -1862,6 +1896,41 @@ static int upload_meshes(const xrt_scene_t* sc, char* ws, int n_runs, KScene* ks
     return 0;
 }
 
+// device copy of the per-bundle plasma model behind the mesh tables; fills KSource.plasma
+static int upload_plasma(const xrt_scene_t* sc, char* ws, int n_runs, KScene* ks, hipStream_t stream)
+{
+    ks->src.plasma = nullptr;
+    const xrt_plasma_t* P = sc->source.plasma;
+    if (!P) return 0;
+    char* base = ws + ws_off_staged(sc, n_runs) + staged_bytes(sc, n_runs) + meshes_bytes(sc);
+    static thread_local KPlasma k;
+    memset(&k, 0, sizeof(k));
+    k.geometry = P->geometry; k.has_spread_radius = P->has_spread_radius; k.n_filters = P->n_filters;
+    k.n_emissivity = P->n_emissivity; k.n_temperature = P->n_temperature;
+    for (int i = 0; i < 3; i++) k.torus_origin[i] = P->torus_origin[i];
+    k.major_radius = P->major_radius; k.minor_radius = P->minor_radius;
+    k.emissivity = P->emissivity; k.emissivity_scale = P->emissivity_scale; k.temperature_scale = P->temperature_scale;
+    k.spread_radius = P->spread_radius; k.solid_angle = P->solid_angle;
+    k.time_resolution = P->time_resolution; k.bundle_volume = P->bundle_volume; k.four_pi = P->four_pi;
+    k.volume_ratio = P->volume_ratio;
+    k.mass_number = P->mass_number; k.amu_kg = P->amu_kg; k.c_squared = P->c_squared; k.ev_J = P->ev_J;
+    for (int i = 0; i < XRT_MAX_BUNDLE_FILTERS; i++) k.filters[i] = P->filters[i];
+    char* p = base + al256(sizeof(KPlasma));
+    auto put = [&](const double* src, int n) -> const double* {
+        char* dst = p;
+        p += al256(sizeof(double) * (size_t)(n > 0 ? n : 1));
+        if (src && n > 0) (void)hipMemcpyAsync(dst, src, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, stream);
+        return reinterpret_cast<const double*>(dst);
+    };
+    k.emissivity_rho = put(P->emissivity_rho, P->n_emissivity);
+    k.emissivity_val = put(P->emissivity_val, P->n_emissivity);
+    k.temperature_rho = put(P->temperature_rho, P->n_temperature);
+    k.temperature_val = put(P->temperature_val, P->n_temperature);
+    HIP_TRY(hipMemcpyAsync(base, &k, sizeof(KPlasma), hipMemcpyHostToDevice, stream));
+    ks->src.plasma = reinterpret_cast<const KPlasma*>(base);
+    return 0;
+}
+
 // uploads of the small tables (pageable host memory -> staged copies, ordered on the stream)
 static int upload_tables(const xrt_scene_t* sc, char* ws, hipStream_t stream)
 {
@@ -1939,8 +2008,17 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
             HIP_TRY(hipEventCreate(&timing_ev[ti][1]));
             HIP_TRY(hipEventRecord(timing_ev[ti][0], stream));
         }
-        if (hist) hipLaunchKernelGGL(xrt_staged_kernel<true>, dim3(slots), dim3(XRT_TILE), lds, stream, ks, a, g);
-        else      hipLaunchKernelGGL(xrt_staged_kernel<false>, dim3(slots), dim3(XRT_TILE), lds, stream, ks, a, g);
+        const bool plasma = sc->source.kind == XRT_SRC_PLASMA;
+        bool special = false;
+        for (int e = 0; e < sc->n_optics; e++)
+            special = special || sc->optics[e].interact == XRT_INTERACT_MOSAIC || sc->optics[e].shape == XRT_SHAPE_MESH ||
+                      (sc->optics[e].flags & XRT_F_TRACE_LOCAL);
+        void (*kern)(const KScene, const KArgs, const KStaged);
+        if (hist) kern = plasma ? (special ? xrt_staged_kernel<true, true, true> : xrt_staged_kernel<true, true, false>)
+                                : (special ? xrt_staged_kernel<true, false, true> : xrt_staged_kernel<true, false, false>);
+        else      kern = plasma ? (special ? xrt_staged_kernel<false, true, true> : xrt_staged_kernel<false, true, false>)
+                                : (special ? xrt_staged_kernel<false, false, true> : xrt_staged_kernel<false, false, false>);
+        hipLaunchKernelGGL(kern, dim3(slots), dim3(XRT_TILE), lds, stream, ks, a, g);
         HIP_TRY(hipGetLastError());
         if (ti >= 0) HIP_TRY(hipEventRecord(timing_ev[ti][1], stream));
         return 0;
@@ -2018,6 +2096,8 @@ extern "C" int xrt_trace(const xrt_scene_t* sc, const uint32_t* seeds, int32_t n
     build_kscene(sc, ws, &ks);
     st = upload_meshes(sc, ws, n_runs, &ks, stream);
     if (st) return st;
+    st = upload_plasma(sc, ws, n_runs, &ks, stream);
+    if (st) return st;
     KArgs a;
     memset(&a, 0, sizeof(a));
     a.num_out = reinterpret_cast<unsigned long long*>(num_out);
@@ -2056,6 +2136,8 @@ extern "C" int xrt_trace_history(const xrt_scene_t* sc, const xrt_rng_state_t* s
     build_kscene(sc, ws, &ks);
     st = upload_meshes(sc, ws, 1, &ks, stream);
     if (st) return st;
+    st = upload_plasma(sc, ws, 1, &ks, stream);
+    if (st) return st;
     KArgs a;
     memset(&a, 0, sizeof(a));
     a.num_out = reinterpret_cast<unsigned long long*>(num_out);
@@ -2079,6 +2161,8 @@ extern "C" int xrt_check(void* workspace, void* stream_)
     uint32_t flags = 0;
     HIP_TRY(hipStreamSynchronize(stream));
     HIP_TRY(hipMemcpy(&flags, reinterpret_cast<char*>(workspace) + 64, sizeof(flags), hipMemcpyDeviceToHost));
+    if (flags & 2u)
+        return fail(-7, "%s", "intensity of less than one encountered. Turn on poisson statistics.");
     if (flags & 1u)
         return fail(-6, "%s", "plasma source produced more rays than the declared capacity (Poisson tail): results are truncated");
     return 0;

@@ -20,7 +20,8 @@ import ctypes as C
 
 import numpy as np
 
-XRT_ABI_VERSION = 9
+XRT_ABI_VERSION = 10
+XRT_MAX_BUNDLE_FILTERS = 4
 XRT_MAX_OPTICS = 16
 XRT_MAX_APERTURES = 8
 XRT_HIST_COMPONENTS = 8
@@ -46,6 +47,24 @@ class Aperture(C.Structure):
                 ('vertices', C.c_double * 6)]
 
 
+class BundleFilter(C.Structure):
+    _fields_ = [('origin', C.c_double * 3), ('zaxis', C.c_double * 3), ('radius', C.c_double)]
+
+
+class Plasma(C.Structure):
+    _fields_ = [('geometry', C.c_int32), ('has_spread_radius', C.c_int32), ('n_filters', C.c_int32),
+                ('n_emissivity', C.c_int32), ('n_temperature', C.c_int32), ('pad', C.c_int32),
+                ('torus_origin', C.c_double * 3), ('major_radius', C.c_double), ('minor_radius', C.c_double),
+                ('emissivity', C.c_double), ('emissivity_scale', C.c_double), ('temperature_scale', C.c_double),
+                ('emissivity_rho', C.POINTER(C.c_double)), ('emissivity_val', C.POINTER(C.c_double)),
+                ('temperature_rho', C.POINTER(C.c_double)), ('temperature_val', C.POINTER(C.c_double)),
+                ('spread_radius', C.c_double), ('solid_angle', C.c_double),
+                ('time_resolution', C.c_double), ('bundle_volume', C.c_double), ('four_pi', C.c_double),
+                ('volume_ratio', C.c_double),
+                ('mass_number', C.c_double), ('amu_kg', C.c_double), ('c_squared', C.c_double), ('ev_J', C.c_double),
+                ('filters', BundleFilter * XRT_MAX_BUNDLE_FILTERS)]
+
+
 class Source(C.Structure):
     _fields_ = [('kind', C.c_int32), ('spatial_dist', C.c_int32),
                 ('angular_dist', C.c_int32), ('wavelength_dist', C.c_int32),
@@ -59,7 +78,8 @@ class Source(C.Structure):
                 ('velocity', C.c_double * 3), ('light_speed', C.c_double),
                 ('voigt_cdf', C.POINTER(C.c_double)), ('voigt_x', C.POINTER(C.c_double)),
                 ('bundle_count', C.c_int64), ('plasma_size', C.c_double * 3),
-                ('bundle_intensity', C.c_double), ('use_poisson', C.c_int32), ('pad_plasma', C.c_int32)]
+                ('bundle_intensity', C.c_double), ('use_poisson', C.c_int32), ('pad_plasma', C.c_int32),
+                ('plasma', C.POINTER(Plasma))]
 
 
 _PD, _PI, _PB = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
@@ -166,17 +186,30 @@ def voigt_cdf_table(gamma, sigma, gridsize=1000, cutoff=1e-5):
     return bounds[1:], cdf
 
 
-def plasma_as_source_param(obj):
+PLASMA_GEOMETRY = {'box': 0, 'toroidal': 1}
+
+
+def _box_distance(obj, point):
+    """Smallest distance from `point` to the plasma box (0 inside): bounds the per-bundle spread."""
+    p = obj.param
+    loc = obj.point_to_local(np.array(point, dtype=np.float64))
+    half = np.array([p['xsize'], p['ysize'], p['zsize']], dtype=np.float64) / 2
+    return float(np.linalg.norm(np.maximum(np.abs(loc) - half, 0.0)))
+
+
+def plasma_as_source_param(obj, keep):
     """
     The parameters every bundle's XicsrtSourceFocused gets from a plasma object
-    (sources/_XicsrtPlasmaGeneric.py:289-336) plus the bundle bookkeeping, for plasmas
-    whose bundles share temperature, emissivity, velocity and spread (XicsrtPlasmaCubic).
+    (sources/_XicsrtPlasmaGeneric.py:289-336) plus the bundle bookkeeping.
+
+    Returns (q, B, lam, plasma): q the focused-source parameters shared by the bundles, B the
+    bundle count, lam the expected rays per bundle when it is one constant, plasma a `Plasma`
+    struct when mask / emissivity / temperature / spread depend on the bundle centre (profile
+    tables, spread_radius, sightline filters), else None.
     """
+    import scipy.constants as const
     p = obj.param
-    if p['spread_radius'] is not None:
-        raise SceneError('plasma spread_radius (per-bundle spread) is not implemented on the device path')
-    if p['spread'] is None:
-        raise Exception('plasma spread is not set')
+    model = obj.bundle_model()
     ad = 'isotropic' if p['angular_dist'] is None else str(p['angular_dist']).lower()
     if ad != 'isotropic':
         raise Exception(f'Solid angle calculation for "{ad}" is not available.')
@@ -187,37 +220,111 @@ def plasma_as_source_param(obj):
     else:
         raise Exception('bundle_type not understood: {}'.format(p['bundle_type']))
     B = int(p['bundle_count'])
-    # setup_bundle_spread + create_sources, per bundle (identical for every bundle here)
-    spread = np.zeros([B], dtype=np.float64)
-    spread[:] = p['spread']
-    spread_b = spread[0]
+    filters = [f for f in obj.filter_objects if f.filter_kind != 'none']
+    if len(filters) > XRT_MAX_BUNDLE_FILTERS:
+        raise SceneError('more than %d bundle filters on one plasma' % XRT_MAX_BUNDLE_FILTERS)
+    per_bundle = (p['spread_radius'] is not None or len(filters) > 0 or
+                  model['emissivity_profile'] is not None or model['temperature_profile'] is not None)
+
+    # setup_bundle_spread (:206-231): one spread for all bundles, or its largest possible value
+    if p['spread_radius'] is not None:
+        dmin = _box_distance(obj, p['target'])
+        spread_b = np.arctan(p['spread_radius'] / dmin) if dmin > 0 else np.pi / 2
+    else:
+        if p['spread'] is None:
+            raise TypeError("unsupported operand type(s) for /: 'NoneType' and 'int'")   # what the reference hits
+        spread = np.zeros([B], dtype=np.float64)
+        spread[:] = p['spread']
+        spread_b = spread[0]
     theta = _parse_spread_single(spread_b)
-    solid_angle = np.zeros([B], dtype=np.float64)
+    solid_angle = np.zeros([1], dtype=np.float64)
     solid_angle[:] = 4 * np.pi * np.sin(theta[0] / 2) ** 2
-    emissivity = np.ones([B], dtype=np.float64)
-    emissivity[:] = p['emissivity']
-    temperature = np.ones([B], dtype=np.float64)
-    temperature[:] = p['temperature']
+
+    # bundle_generate: emissivity / temperature of a bundle (constants, or an upper bound)
+    emissivity = np.ones([1], dtype=np.float64)
+    temperature = np.ones([1], dtype=np.float64)
+    if model['geometry'] == 'toroidal':
+        if model['emissivity_profile'] is None:
+            emissivity[:] = model['emissivity'] * model['emissivity_scale']
+        else:
+            emissivity[:] = np.max(model['emissivity_profile'][1]) * model['emissivity_scale']
+        if model['temperature_profile'] is None:
+            temperature[:] = model['temperature'] * model['temperature_scale']
+        if not np.all(np.isfinite(temperature)):
+            raise ValueError('No rays generated. Check plasma input parameters')
+    else:
+        emissivity[:] = model['emissivity']
+        temperature[:] = model['temperature']
     intensity = (emissivity[0] * p['time_resolution'] * p['bundle_volume'] * solid_angle[0] / (4 * np.pi))
     intensity *= p['volume'] / (p['bundle_count'] * p['bundle_volume'])
-    predicted_rays = int(np.sum(emissivity * p['time_resolution'] * p['bundle_volume'] * solid_angle / (4 * np.pi)
-                                * p['volume'] / (p['bundle_count'] * p['bundle_volume'])))
-    if p['max_rays']:
-        if predicted_rays > p['max_rays']:
+    predicted_rays = int(B * (emissivity[0] * p['time_resolution'] * p['bundle_volume'] * solid_angle[0] / (4 * np.pi)
+                              * p['volume'] / (p['bundle_count'] * p['bundle_volume'])))
+    if p['max_rays'] and predicted_rays > p['max_rays']:
+        if not per_bundle:
             raise ValueError(f"Current settings will produce too many rays ({predicted_rays:0.2e}). "
                              f"Please reduce integration time or adjust other parameters.")
+        predicted_rays = int(p['max_rays'])      # an upper bound only; the device flags an overflow
     if p['use_poisson']:
         capacity = int(predicted_rays + 12 * np.sqrt(max(predicted_rays, 1)) + 4096)
     else:
-        if intensity < 1:
+        if intensity < 1 and not per_bundle:
             raise ValueError('intensity of less than one encountered. Turn on poisson statistics.')
-        capacity = B * int(intensity)
+        capacity = max(B * int(intensity), 1)
     q = {'xsize': voxel_size, 'ysize': voxel_size, 'zsize': voxel_size, 'spatial_dist': 'uniform',
          'angular_dist': ad, 'spread': spread_b, 'intensity': capacity, 'zaxis': p['zaxis'], 'xaxis': p['xaxis'],
          'wavelength_dist': p['wavelength_dist'], 'wavelength': p['wavelength'],
          'wavelength_range': p['wavelength_range'], 'linewidth': p['linewidth'], 'mass_number': p['mass_number'],
-         'temperature': temperature[0], 'velocity': np.zeros(3), 'target': p['target']}
-    return q, B, float(intensity)
+         'temperature': temperature[0], 'velocity': np.asarray(model['velocity'], dtype=np.float64),
+         'target': p['target']}
+    if not per_bundle:
+        return q, B, float(intensity), None
+
+    pl = Plasma()
+    pl.geometry = PLASMA_GEOMETRY[model['geometry']]
+    pl.has_spread_radius = int(p['spread_radius'] is not None)
+    pl.spread_radius = float(p['spread_radius']) if p['spread_radius'] is not None else 0.0
+    pl.solid_angle = float(solid_angle[0])
+    _vec(pl.torus_origin, model.get('torus_origin', np.zeros(3)))
+    pl.major_radius = float(model.get('major_radius', 0.0))
+    pl.minor_radius = float(model.get('minor_radius', 0.0))
+    pl.emissivity = float(model['emissivity'])
+    pl.emissivity_scale = float(model['emissivity_scale'])
+    pl.temperature_scale = float(model['temperature_scale'])
+    if model['geometry'] == 'toroidal' and model['emissivity_profile'] is None:
+        pl.emissivity = float(model['emissivity'])
+    for which in ('emissivity', 'temperature'):
+        prof = model[which + '_profile']
+        n = 0
+        if prof is not None:
+            x = np.ascontiguousarray(prof[0], dtype=np.float64)
+            y = np.ascontiguousarray(prof[1], dtype=np.float64)
+            keep.extend([x, y])
+            n = len(x)
+            setattr(pl, which + '_rho', x.ctypes.data_as(C.POINTER(C.c_double)))
+            setattr(pl, which + '_val', y.ctypes.data_as(C.POINTER(C.c_double)))
+        setattr(pl, 'n_' + which, n)
+    if pl.n_temperature > 0:
+        wtype = str.lower(p['wavelength_dist'])
+        if wtype == 'voigt' and p['linewidth'] != 0.0:
+            raise SceneError('a temperature profile together with a natural linewidth needs one Voigt table '
+                             'per bundle; not implemented on the device path')
+        q['temperature'] = 1.0          # placeholder: selects the Gaussian case, sigma comes per bundle
+    pl.time_resolution = float(p['time_resolution'])
+    pl.bundle_volume = float(p['bundle_volume'])
+    pl.four_pi = float(4 * np.pi)
+    pl.volume_ratio = float(p['volume'] / (p['bundle_count'] * p['bundle_volume']))
+    pl.mass_number = float(p['mass_number'])
+    pl.amu_kg = float(const.physical_constants['atomic mass unit-kilogram relationship'][0])
+    pl.ev_J = float(const.physical_constants['electron volt-joule relationship'][0])
+    pl.c_squared = float(const.physical_constants['speed of light in vacuum'][0] ** 2)
+    pl.n_filters = len(filters)
+    for i, f in enumerate(filters):
+        origin, zaxis, radius = f.sightline()
+        _vec(pl.filters[i].origin, origin)
+        _vec(pl.filters[i].zaxis, zaxis)
+        pl.filters[i].radius = float(radius)
+    keep.append(pl)
+    return q, B, float(intensity), pl
 
 
 def flatten_source(obj, out, keep):
@@ -227,8 +334,13 @@ def flatten_source(obj, out, keep):
     _vec(out.plasma_size, np.zeros(3))
     out.bundle_intensity = 0.0
     out.use_poisson = 0
+    out.plasma = None
+    if obj.cone_axis_rule != 'plasma' and len(getattr(obj, 'filter_objects', [])) > 0:
+        raise SceneError('ray filters on a non-plasma source are not implemented on the device path')
     if obj.cone_axis_rule == 'plasma':
-        q, B, lam = plasma_as_source_param(obj)
+        q, B, lam, pl = plasma_as_source_param(obj, keep)
+        if pl is not None:
+            out.plasma = C.pointer(pl)
         out.bundle_count = B
         _vec(out.plasma_size, [p['xsize'], p['ysize'], p['zsize']])
         out.bundle_intensity = lam

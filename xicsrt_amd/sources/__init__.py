@@ -8,6 +8,9 @@ of the reference; the per-ray sampling itself runs on the device.
                         (xicsrt/sources/_XicsrtSourceDirected.py:16-50)
   XicsrtSourceFocused   cone aimed at `target` from every origin
                         (xicsrt/sources/_XicsrtSourceFocused.py:16-44)
+  XicsrtPlasmaGeneric / Cubic / Toroidal / ToroidalDatafile
+                        plasma volumes emitting from random bundles
+                        (xicsrt/sources/_XicsrtPlasma*.py)
 """
 import numpy as np
 
@@ -180,10 +183,94 @@ class XicsrtPlasmaGeneric(GeometryObject):
         from .. import xicsrt_raytrace as _rt
         return _rt.generate_rays_from_global_state(self)
 
+    def bundle_model(self):
+        """
+        What bundle_generate() of the class assigns to every unmasked bundle, as data for the
+        device: geometry of the flux coordinate ('box': none), emissivity / temperature either
+        constants or (rho, value) profile tables with a scale, and the bundle velocity.
+        The base class leaves the set-up defaults: emissivity 1, temperature 1, velocity 0
+        (sources/_XicsrtPlasmaGeneric.py:186-190, :238-240).
+        """
+        return {'geometry': 'box', 'emissivity': 1.0, 'temperature': 1.0, 'velocity': np.zeros(3),
+                'emissivity_scale': 1.0, 'temperature_scale': 1.0,
+                'emissivity_profile': None, 'temperature_profile': None}
+
 
 class XicsrtPlasmaCubic(XicsrtPlasmaGeneric):
     """A cuboid plasma with constant temperature and emissivity (sources/_XicsrtPlasmaCubic.py:16-35)."""
 
+    def bundle_model(self):
+        m = super().bundle_model()
+        m['temperature'] = self.param['temperature']
+        m['emissivity'] = self.param['emissivity']
+        return m
+
+
+class XicsrtPlasmaToroidal(XicsrtPlasmaGeneric):
+    """
+    Toroidal geometry with a circular cross-section (sources/_XicsrtPlasmaToroidal.py:19-78): every
+    bundle gets emissivity, temperature and velocity from its normalised radius
+    rho = sqrt(r_minor^2 / minor_radius), times the *_scale factors; bundles with a non-finite
+    temperature are dropped.
+    """
+
+    def default_config(self):
+        """major_radius, minor_radius, torus_origin, emissivity_scale, temperature_scale, velocity_scale"""
+        config = super().default_config()
+        config['major_radius'] = 0.0
+        config['minor_radius'] = 0.0
+        config['torus_origin'] = np.array([0.0, 0.0, 0.0])
+        config['emissivity_scale'] = 1.0
+        config['temperature_scale'] = 1.0
+        config['velocity_scale'] = 1.0
+        return config
+
+    def profile(self, which):
+        """(rho, value) table of get_<which>(rho), or None when it is the constant param[which]."""
+        return None
+
+    def bundle_model(self):
+        p = self.param
+        m = super().bundle_model()
+        m['geometry'] = 'toroidal'
+        m['torus_origin'] = np.asarray(p['torus_origin'], dtype=np.float64)
+        m['major_radius'] = p['major_radius']
+        m['minor_radius'] = p['minor_radius']
+        m['emissivity'] = p['emissivity']
+        m['temperature'] = p['temperature']
+        m['emissivity_scale'] = p['emissivity_scale']
+        m['temperature_scale'] = p['temperature_scale']
+        m['emissivity_profile'] = self.profile('emissivity')
+        m['temperature_profile'] = self.profile('temperature')
+        # get_velocity(rho) * velocity_scale broadcast into the (n, 3) bundle array (:72)
+        vel = np.zeros((1, 3), dtype=np.float64)
+        vel[:] = p['velocity'] * p['velocity_scale']
+        m['velocity'] = vel[0]
+        return m
+
+
+class XicsrtPlasmaToroidalDatafile(XicsrtPlasmaToroidal):
+    """
+    Toroidal plasma whose emissivity and temperature profiles are read from two-column text files
+    (rho, value), np.interp with zero outside the table (sources/_XicsrtPlasmaToroidalDatafile.py:21-45).
+    `velocity_file` is a config key of the reference that it never reads.
+    """
+
+    def default_config(self):
+        """emissivity_file, temperature_file, velocity_file"""
+        config = super().default_config()
+        config['emissivity_file'] = None
+        config['temperature_file'] = None
+        config['velocity_file'] = None
+        return config
+
+    def profile(self, which):
+        if which not in ('emissivity', 'temperature'):
+            return None
+        data = np.loadtxt(self.param[which + '_file'], dtype=np.float64)
+        return (np.ascontiguousarray(data[:, 0]), np.ascontiguousarray(data[:, 1]))
+
 
 BUILTIN = {cls.__name__: cls for cls in (XicsrtSourceGeneric, XicsrtSourceDirected, XicsrtSourceFocused,
-                                         XicsrtPlasmaGeneric, XicsrtPlasmaCubic)}
+                                         XicsrtPlasmaGeneric, XicsrtPlasmaCubic, XicsrtPlasmaToroidal,
+                                         XicsrtPlasmaToroidalDatafile)}

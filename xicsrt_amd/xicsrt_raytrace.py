@@ -39,6 +39,7 @@ from . import scene as xscene
 from .objects import RayArray
 from . import sources as _sources
 from . import optics as _optics
+from . import filters as _filters
 
 m_log = logging.getLogger('xicsrt')
 
@@ -55,6 +56,8 @@ def _builtin_registry(section):
         return _sources.BUILTIN
     if section == 'optics':
         return _optics.BUILTIN
+    if section == 'filters':
+        return _filters.BUILTIN
     return {}
 
 
@@ -72,7 +75,8 @@ def find_class(class_name, section, pathlist):
             mod = importlib.util.module_from_spec(spec)
             spec.loader.exec_module(mod)
             cls = getattr(mod, class_name)
-            base = (_sources.XicsrtSourceGeneric, _sources.XicsrtPlasmaGeneric) if section == 'sources' else _optics.TraceObject
+            base = {'sources': (_sources.XicsrtSourceGeneric, _sources.XicsrtPlasmaGeneric),
+                    'filters': _filters.XicsrtBundleFilter}.get(section, _optics.TraceObject)
             if not issubclass(cls, base):
                 raise NotImplementedError(
                     'User plug-in %s (%s) is not built from xicsrt_amd element classes; arbitrary NumPy '
@@ -93,8 +97,6 @@ class Elements:
         general = config['general']
         strict = general['strict_config_check']
         pathlist = list(general.get('pathlist', []) or [])
-        if config.get('filters'):
-            raise NotImplementedError('ray/bundle filters are not implemented on the device path yet.')
         sources = config['sources']
         if len(sources) == 0:
             raise Exception('No ray sources defined.')
@@ -103,15 +105,28 @@ class Elements:
         self.objects = {}
         self.source_name = list(sources.keys())[0]
         built = {}
-        for section in ('sources', 'optics'):
+        for section in ('filters', 'sources', 'optics'):
             objs = {}
-            for key, sub in config[section].items():
+            for key, sub in (config.get(section) or {}).items():
                 cls = find_class(sub['class_name'], section, pathlist)
                 objs[key] = cls(sub, initialize=False, strict=strict)
+            if section != 'filters':
+                # Dispatcher.apply_filters (objects/_Dispatcher.py:198-211): filters named in an
+                # element's `filters` list are attached in the order of the filters section
+                for obj in objs.values():
+                    wanted = obj.config.get('filters') if hasattr(obj.config, 'get') else None
+                    if wanted is None:
+                        continue
+                    for fname, fobj in built['filters'].items():
+                        if fname in wanted:
+                            obj.filter_objects.append(fobj)
             for method in ('setup', 'check_param', 'initialize'):
+                if section == 'filters' and method == 'check_param':
+                    continue                                     # (xicsrt_raytrace.py:125-128)
                 for obj in objs.values():
                     getattr(obj, method)()
             built[section] = objs
+        self.filters = built['filters']
         self.source = built['sources'][self.source_name]
         self.optic_names = list(built['optics'].keys())
         self.optics = [built['optics'][k] for k in self.optic_names]
