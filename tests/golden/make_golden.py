@@ -444,7 +444,7 @@ def dump_class_defaults():
     out = {'general': _jsonable({k: v for k, v in xicsrt_config.default_config()['general'].items()
                                  if k != 'pathlist_default'})}
     base = os.path.join(REFERENCE, 'xicsrt')
-    for section in ('sources', 'optics'):
+    for section in ('sources', 'optics', 'filters'):
         out[section] = {}
         for path in sorted(glob.glob(os.path.join(base, section, '_Xicsrt*.py'))):
             name = os.path.splitext(os.path.basename(path))[0][1:]
@@ -535,5 +535,38 @@ def main(argv):
     json.dump(index, open(index_path, 'w'), indent=1, sort_keys=True)
 
 
+def dump_io_cases():
+    """File-name rules, the saved-config text and a saved image of the reference's xicsrt_io (data fixtures)."""
+    from xicsrt import xicsrt_io
+    import tempfile
+    from PIL import Image
+    out = {'filenames': []}
+    for general, kind, name in [({'output_path': '/tmp/x'}, 'config', None),
+                                ({'output_path': 'out', 'output_prefix': 'run', 'output_suffix': 'a1'}, 'image', 'detector'),
+                                ({'output_path': 'out', 'output_run_suffix': '0003', 'results_ext': '.json'}, 'results', None),
+                                ({'output_path': '', 'output_prefix': None, 'output_suffix': 's'}, None, 'thing')]:
+        out['filenames'].append({'general': general, 'kind': kind, 'name': name,
+                                 'expected': xicsrt_io.generate_filename({'general': dict(general)}, kind, name)})
+    cfg = cfg_three(1000, _crystal('XicsrtOpticSphericalCrystal', radius=1.0, **_BRAGG), seed=5)
+    cfg = xicsrt_config.get_config(xicsrt_config.config_to_numpy(copy.deepcopy(cfg)))
+    with tempfile.TemporaryDirectory() as tmp:
+        cfg['general']['output_path'] = tmp
+        xicsrt_io.save_config(cfg)
+        out['config_in'] = _jsonable(cfg)
+        out['config_text'] = open(os.path.join(tmp, 'xicsrt_config.json')).read().replace(tmp, '<TMP>')
+        img = np.arange(12, dtype=np.float64).reshape(4, 3)
+        res = {'config': cfg, 'total': {'image': {'crystal': img, 'detector': None}}}
+        xicsrt_io.save_images(res)
+        back = np.array(Image.open(os.path.join(tmp, 'xicsrt_crystal.tif')))
+        out['image_in'] = img.tolist()
+        out['image_file_pixels'] = back.tolist()
+        out['image_file_dtype'] = str(back.dtype)
+    json.dump(out, open(os.path.join(HERE, 'io_cases.json'), 'w'), indent=1)
+    print('io_cases.json written')
+
+
 if __name__ == '__main__':
-    main(sys.argv)
+    if len(sys.argv) > 1 and sys.argv[1] == 'io_cases':
+        dump_io_cases()
+    else:
+        main(sys.argv)

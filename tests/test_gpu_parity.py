@@ -170,3 +170,25 @@ def test_source_object_generate_rays_uses_global_numpy_state(devlib):
     ref = np.random.RandomState(cfg['general']['random_seed'])
     ref.random_sample(5 * 500)
     assert after == ref.random_sample()
+
+
+@pytest.mark.gpu
+def test_save_options_write_the_reference_files(tmp_path):
+    """save_config / save_images / save_results at the end of raytrace(); per-run images carry the run suffix
+    and add up to the combined image (xicsrt_raytrace.py:74-81, :169-170)."""
+    from PIL import Image
+    import xicsrt_amd
+    cfg, gold = helpers.load_golden('C_sphere_runs')
+    cfg['general'].update(save_config=True, save_images=True, save_results=True, results_ext='.json',
+                          output_path=str(tmp_path), number_of_runs=3)
+    res = xicsrt_amd.raytrace(cfg)
+    files = sorted(os.listdir(tmp_path))
+    assert files == ['xicsrt_config.json', 'xicsrt_crystal.tif', 'xicsrt_crystal_0000.tif', 'xicsrt_crystal_0001.tif',
+                     'xicsrt_crystal_0002.tif', 'xicsrt_detector.tif', 'xicsrt_detector_0000.tif',
+                     'xicsrt_detector_0001.tif', 'xicsrt_detector_0002.tif', 'xicsrt_results.json']
+    total = np.array(Image.open(tmp_path / 'xicsrt_detector.tif'))
+    assert np.array_equal(total, np.rot90(res['total']['image']['detector']).astype(np.float32))
+    parts = sum(np.array(Image.open(tmp_path / ('xicsrt_detector_%04d.tif' % i))) for i in range(3))
+    assert np.array_equal(parts, total)
+    back = xicsrt_amd.xicsrt_io.load_results(config=res['config'])
+    assert back['total']['meta']['detector']['num_out'] == res['total']['meta']['detector']['num_out']

@@ -37,7 +37,7 @@ def test_element_class_defaults_match_reference():
     """Every built-in class offered here has exactly the reference's default_config (keys and values)."""
     ref = json.load(open(os.path.join(helpers.GOLDEN, 'class_defaults.json')))
     checked = 0
-    for section in ('sources', 'optics'):
+    for section in ('sources', 'optics', 'filters'):
         for name, expected in ref[section].items():
             try:
                 cls = xrt.find_class(name, section, [])
@@ -50,7 +50,7 @@ def test_element_class_defaults_match_reference():
             assert got == expected, name
             assert list(got.keys()) == list(got.keys())
             checked += 1
-    assert checked >= 12
+    assert checked >= 25
 
 
 def test_strict_config_check_and_merge():

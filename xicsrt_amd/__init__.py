@@ -14,6 +14,7 @@ import logging as _logging
 from .config import __version__
 from .xicsrt_raytrace import raytrace, raytrace_mp, raytrace_single, combine_raytrace  # noqa: F401
 from . import config as xicsrt_config  # noqa: F401
+from . import xicsrt_io  # noqa: F401
 
 
 def get_element(config_user, name, section=None, initialize=True):

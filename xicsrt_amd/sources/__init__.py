@@ -206,6 +206,17 @@ class XicsrtPlasmaCubic(XicsrtPlasmaGeneric):
         return m
 
 
+class XicsrtPlasmaCylindrical(XicsrtPlasmaGeneric):
+    """
+    Present for the class-name surface only: the reference's class is marked broken and fails in
+    bundle_generate with AttributeError('emissivity') (sources/_XicsrtPlasmaCylindrical.py:18-55,
+    it reads self.emissivity, which no object defines); the same error is raised here.
+    """
+
+    def bundle_model(self):
+        raise AttributeError('emissivity')
+
+
 class XicsrtPlasmaToroidal(XicsrtPlasmaGeneric):
     """
     Toroidal geometry with a circular cross-section (sources/_XicsrtPlasmaToroidal.py:19-78): every
@@ -272,5 +283,5 @@ class XicsrtPlasmaToroidalDatafile(XicsrtPlasmaToroidal):
 
 
 BUILTIN = {cls.__name__: cls for cls in (XicsrtSourceGeneric, XicsrtSourceDirected, XicsrtSourceFocused,
-                                         XicsrtPlasmaGeneric, XicsrtPlasmaCubic, XicsrtPlasmaToroidal,
+                                         XicsrtPlasmaGeneric, XicsrtPlasmaCubic, XicsrtPlasmaCylindrical, XicsrtPlasmaToroidal,
                                          XicsrtPlasmaToroidalDatafile)}

@@ -40,6 +40,7 @@ from .objects import RayArray
 from . import sources as _sources
 from . import optics as _optics
 from . import filters as _filters
+from . import xicsrt_io
 
 m_log = logging.getLogger('xicsrt')
 
@@ -473,28 +474,69 @@ def _max_lost_iter(general, internal):
     return max(int(max_lost), 1)
 
 
-def _raytrace_runs(config, run_indices, seeds, internal):
+class _RunImageWriter:
+    """
+    The reference writes every run's own images when `save_images` is set (raytrace_single,
+    xicsrt_raytrace.py:169-170, file names carry the run suffix).  The device accumulates over
+    runs, so the image of one run is the difference of the totals before and after it.
+    """
+
+    def __init__(self, config, device):
+        self.config, self.device = config, device
+        self.previous = None
+
+    def __call__(self, run_index):
+        meta, image = self.device.results()
+        delta = {}
+        for name, img in image.items():
+            if img is None:
+                delta[name] = None
+            elif self.previous is None or self.previous.get(name) is None:
+                delta[name] = img.copy()
+            else:
+                delta[name] = img - self.previous[name]
+        self.previous = image
+        cfg = copy.deepcopy(self.config)
+        cfg['general']['output_run_suffix'] = '{:04d}'.format(run_index)
+        xicsrt_io.save_images({'config': cfg, 'total': {'image': delta}})
+
+
+def _raytrace_runs(config, run_indices, seeds, internal, per_run_images=False):
     """Trace the given runs on this process' device; returns one combined result dict."""
     config, elements = _prepare(config)
     general = config['general']
     flat = elements.flatten()
     device = DeviceTrace(flat)
     my_seeds = [seeds[i] for i in run_indices]
+    after_run = _RunImageWriter(config, device) if per_run_images else None
     if general['keep_history']:
         max_lost = _max_lost_iter(general, internal)
-        outputs = [_run_with_history(config, elements, device, s, max_lost) for s in my_seeds]
+        outputs = []
+        for i, s in zip(run_indices, my_seeds):
+            outputs.append(_run_with_history(config, elements, device, s, max_lost))
+            if after_run:
+                after_run(i)
         if not outputs:
             return None, device, config
         return combine_raytrace(outputs), device, config
-    device.trace(my_seeds, general['number_of_iter'], general['keep_images'])
+    if after_run:
+        for i, s in zip(run_indices, my_seeds):
+            device.trace([s], general['number_of_iter'], general['keep_images'])
+            after_run(i)
+    else:
+        device.trace(my_seeds, general['number_of_iter'], general['keep_images'])
     return None, device, config
 
 
 def _finish(output, config_user_general):
+    """Saving and printing at the end of raytrace() / raytrace_single() (xicsrt_raytrace.py:74-81, :163-170)."""
     general = output['config']['general']
-    if general['save_config'] or general['save_images'] or general['save_results']:
-        raise NotImplementedError('save_config/save_images/save_results are outside the device path '
-                                  '(reference xicsrt_io); save the returned dictionary instead.')
+    if general['save_config']:
+        xicsrt_io.save_config(output['config'])
+    if general['save_images']:
+        xicsrt_io.save_images(output)
+    if general['save_results']:
+        xicsrt_io.save_results(output)
     if general['print_results']:
         print_raytrace(output)
     return output
@@ -517,7 +559,8 @@ def raytrace(config):
     dist, rank, world = _dist()
     indices = shard_runs(num_runs, rank, world)
 
-    hist_output, device, cfg = _raytrace_runs(copy.deepcopy(config_in), indices, seeds, internal=True)
+    hist_output, device, cfg = _raytrace_runs(copy.deepcopy(config_in), indices, seeds, internal=True,
+                                              per_run_images=bool(general['save_images']))
 
     t = device.torch
     if dist is not None and world > 1:
