@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define XRT_ABI_VERSION 10
+#define XRT_ABI_VERSION 11
 
 #define XRT_MAX_OPTICS     16
 #define XRT_MAX_APERTURES  8
@@ -51,7 +51,9 @@ extern "C" {
 /* cone-axis rule of the source (sources/_XicsrtSourceGeneric.py:262,
  * _XicsrtSourceDirected.py:46, _XicsrtSourceFocused.py:40) */
 enum { XRT_SRC_GENERIC = 0, XRT_SRC_DIRECTED = 1, XRT_SRC_FOCUSED = 2,
-       XRT_SRC_PLASMA = 3   /* XicsrtPlasma*: bundles of focused sources (sources/_XicsrtPlasmaGeneric.py:252-382) */ };
+       XRT_SRC_PLASMA = 3,  /* XicsrtPlasma*: bundles of focused sources (sources/_XicsrtPlasmaGeneric.py:252-382) */
+       XRT_SRC_EXTERNAL = 4 /* rays supplied by the caller: TraceObject.trace_global(rays) on a user's ray
+                             * array (optics/_TraceObject.py:135-154); xrt_trace_history only */ };
 /* spatial_dist (_XicsrtSourceGeneric.py:231,237) */
 enum { XRT_SPATIAL_UNIFORM = 0, XRT_SPATIAL_GAUSSIAN = 1 };
 /* angular_dist (tools/xicsrt_spread.py:21) */
@@ -179,6 +181,11 @@ typedef struct xrt_source {
     int32_t use_poisson;      /* np.random.poisson(intensity) per bundle, else int(intensity) */
     int32_t pad_plasma;
     const xrt_plasma_t* plasma;   /* HOST pointer or NULL: per-bundle model, see xrt_plasma_t   */
+    /* XRT_SRC_EXTERNAL only: `intensity` rays in DEVICE memory, component-major
+     * ext_rays[c * intensity + i], c = ox,oy,oz,dx,dy,dz,wavelength,weight; ext_mask[i] != 0: alive.
+     * Rays with mask 0 do not take part (RayArray 'mask', objects/_RayArray.py:12-96). */
+    const double*  ext_rays;
+    const uint8_t* ext_mask;
 } xrt_source_t;
 
 /* A triangulated-mesh surface (optics/_ShapeMesh.py:198-261 _mesh_precalc output), all HOST
@@ -325,6 +332,13 @@ int xrt_trace_history(const xrt_scene_t* scene, const xrt_rng_state_t* state_in,
                       double* rays, uint8_t* mask, void* state_out,
                       void* workspace, size_t workspace_bytes,
                       void* stream);
+
+/* TraceObject.make_image(rays) (optics/_TraceObject.py:234-293) for a caller's ray array: every ray
+ * with mask[i] != 0 adds one count to the optic's pixel bin of its origin, images[image_offset +
+ * cx * pixel_ny + cy].  rays: DEVICE, component-major [8][n] as xrt_source_t.ext_rays (only the
+ * three origin rows are read); mask, images: DEVICE.  Asynchronous on `stream`. */
+int xrt_make_image(const xrt_optic_t* optic, int64_t n, const double* rays, const uint8_t* mask,
+                   uint64_t* images, void* stream);
 
 /* Synchronises `stream` and reports conditions the asynchronous calls could only flag on the
  * device (a plasma source that produced more rays than the declared capacity): 0 = clean. */

@@ -515,6 +515,16 @@ static int bundle_eval(const xrt_source_t* s, const double* c, xrt_source_t* sb,
  * Returns the number of rays generated (<= capacity r->n) or -1 on overflow. */
 static int64_t generate_rays(const xrt_source_t* s, mt_t* mt, rays_t* r)
 {
+    if (s->kind == XRT_SRC_EXTERNAL) {      /* the caller's rays (host pointers here), dead ones included */
+        const int64_t n = r->n;
+        for (int64_t i = 0; i < n; i++) {
+            for (int k = 0; k < 3; k++) { r->o[3 * i + k] = s->ext_rays[k * n + i]; r->d[3 * i + k] = s->ext_rays[(3 + k) * n + i]; }
+            r->wl[i] = s->ext_rays[6 * n + i];
+            r->wt[i] = s->ext_rays[7 * n + i];
+            r->mask[i] = s->ext_mask[i] != 0;
+        }
+        return n;
+    }
     if (s->kind != XRT_SRC_PLASMA) {
         generate_block(s, s->origin, mt, r, 0, r->n);
         return r->n;
@@ -1193,12 +1203,12 @@ static void make_image(const xrt_optic_t* op, const rays_t* r, uint64_t* img)
     }
 }
 
-static void save_history(const rays_t* r, int64_t stride, int e, double* hist, uint8_t* hmask)
+static void save_history(const rays_t* r, int64_t stride, int e, double* hist, uint8_t* hmask, int all_at_source)
 {
     const int64_t n = stride;
     for (int64_t i = 0; i < r->n; i++) {
         hmask[(int64_t)e * n + i] = r->mask[i];
-        if (!r->mask[i] && !(e > 0 && r->prev[i])) continue;   /* alive, or died at this element */
+        if (!r->mask[i] && !(e > 0 && r->prev[i]) && !(e == 0 && all_at_source)) continue;   /* alive, or died at this element */
         double* h = hist + (int64_t)e * XRT_HIST_COMPONENTS * n;
         for (int k = 0; k < 3; k++) { h[k * n + i] = r->o[3 * i + k]; h[(3 + k) * n + i] = r->d[3 * i + k]; }
         h[6 * n + i] = r->wl[i];
@@ -1219,15 +1229,16 @@ static int run_single(const xrt_scene_t* sc, mt_t* mtp, int n_iter,
         if (produced < 0) { rays_free(&r); return -3; }
         const int64_t stride = r.n;
         r.n = produced;
-        num_out[0] += (uint64_t)r.n;
-        if (hist) save_history(&r, stride, 0, hist, hmask);
+        if (sc->source.kind == XRT_SRC_EXTERNAL) { for (int64_t i = 0; i < r.n; i++) num_out[0] += r.mask[i]; }
+        else num_out[0] += (uint64_t)r.n;
+        if (hist) save_history(&r, stride, 0, hist, hmask, sc->source.kind == XRT_SRC_EXTERNAL);
         for (int e = 0; e < sc->n_optics; e++) {
             const xrt_optic_t* op = &sc->optics[e];
             trace_optic(op, &r, &mt);
             uint64_t c = 0;
             for (int64_t i = 0; i < r.n; i++) c += r.mask[i];
             num_out[e + 1] += c;
-            if (hist) save_history(&r, stride, e + 1, hist, hmask);
+            if (hist) save_history(&r, stride, e + 1, hist, hmask, 0);
             make_image(op, &r, images);
         }
     }

@@ -336,6 +336,12 @@ def build_cases():
     add('F_generic_plasma_trace', 'trace', cfg_three(0, sph, source=dict(box, class_name='XicsrtPlasmaGeneric',
                                                                         time_resolution=3e9), history=True, seed=69))
 
+    # --- object-level API: generate_rays / trace_global / make_image on a caller's ray array ----
+    add('O_object_sphere', 'object', cfg_three(4000, dict(sph, rocking_fwhm=2e-3), seed=91))
+    add('O_object_mirror_local', 'object', cfg_three(3000, dict(mir, trace_local=True), seed=92))
+    add('O_object_torus', 'object', cfg_three(2000, _crystal('XicsrtOpticToroidalCrystal', radius_major=1.0, radius_minor=0.5,
+                                                             **dict(_BRAGG, rocking_fwhm=5e-3)), seed=93))
+
     # --- mesh set-up tables of the three generators (host-side parity) -----------
     for cls, extra in [('XicsrtOpticMeshToroidalCrystal', {'radius_major': 1.0, 'radius_minor': 0.2, 'mesh_size': [9, 7]}),
                        ('XicsrtOpticMeshSphericalCrystal', {'radius': 1.3, 'mesh_size': [8, 6]}),
@@ -518,7 +524,8 @@ def main(argv):
     for name in want:
         kind, cfg = cases[name]
         try:
-            out = {'trace': run_trace, 'counts': run_counts, 'history': run_history, 'mesh': run_mesh_tables}[kind](cfg)
+            out = {'trace': run_trace, 'counts': run_counts, 'history': run_history, 'mesh': run_mesh_tables,
+                   'object': run_object}[kind](cfg)
         except Exception as e:  # reference raised: record that, it is part of the contract
             print('%-32s REFERENCE RAISED %s: %s' % (name, type(e).__name__, e))
             continue
@@ -533,6 +540,27 @@ def main(argv):
                        'bytes': os.path.getsize(path)}
         print('%-32s %s' % (name, counts))
     json.dump(index, open(index_path, 'w'), indent=1, sort_keys=True)
+
+
+def run_object(cfg):
+    """Object-level API: source.generate_rays(), some rays switched off by the caller, then
+    optic.trace_global(rays) and optic.make_image(rays) (xicsrt_public.get_element objects)."""
+    cfg = _ref_cfg(cfg)
+    np.random.seed(cfg['general']['random_seed'])
+    source = xicsrt.get_element(cfg, 'source')
+    crystal = xicsrt.get_element(cfg, 'crystal')
+    rays = source.generate_rays()
+    rays['mask'][::5] = False
+    out = {'names': np.array(['source', 'crystal'])}
+    for k in ('origin', 'direction', 'wavelength', 'mask'):
+        out['in/' + k] = np.array(rays[k])
+    rays = crystal.trace_global(rays)
+    for k in ('origin', 'direction', 'wavelength', 'mask'):
+        out['out/' + k] = np.array(rays[k])
+    img = crystal.make_image(rays)
+    out['image'] = img.astype(np.int64)
+    out['next_double'] = np.float64(np.random.random_sample())
+    return out
 
 
 def dump_io_cases():

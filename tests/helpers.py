@@ -105,7 +105,7 @@ def oracle_counts(flat, seeds, n_iter, threads=1):
     return num_out.astype(np.int64), images.astype(np.int64)
 
 
-def oracle_history(flat, state):
+def oracle_history(flat, state, all_rays=False):
     L = load_oracle()
     n, ne = flat.n_rays, flat.n_elements
     num_out = np.zeros(ne, dtype=np.uint64)
@@ -116,7 +116,8 @@ def oracle_history(flat, state):
     st = L.xrt_oracle_trace_history(flat.byref(), C.byref(state), num_out.ctypes.data, images.ctypes.data,
                                     rays.ctypes.data, mask.ctypes.data, C.byref(out))
     assert st == 0
-    n = int(mask[0].sum())      # plasma sources: drawn ray count, n_rays is the capacity
+    if not all_rays:
+        n = int(mask[0].sum())  # plasma sources: drawn ray count, n_rays is the capacity
     return num_out.astype(np.int64), images.astype(np.int64), rays[:, :, :n], mask[:, :n].astype(bool), out
 
 
@@ -138,7 +139,7 @@ def assert_history_matches_golden(flat, rays, mask, gold, rtol=1e-12):
     vector's magnitude); rays that died at an element carry the point they
     died at, NaN pattern included.
     """
-    hist = xrt._history_from_device(flat.names, rays, mask)
+    hist = xrt._history_from_device(flat.names, rays, mask, flat.optic_objs)
     for name in flat.names:
         gm = gold['mask/' + name]
         assert np.array_equal(hist[name]['mask'], gm), 'mask mismatch at %s' % name

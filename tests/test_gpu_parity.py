@@ -7,6 +7,7 @@ bit-exact; ray positions/directions/wavelengths within FLOAT_RTOL relative
 device's sin/cos/asin/acos/exp/atan).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -192,3 +193,29 @@ def test_save_options_write_the_reference_files(tmp_path):
     assert np.array_equal(parts, total)
     back = xicsrt_amd.xicsrt_io.load_results(config=res['config'])
     assert back['total']['meta']['detector']['num_out'] == res['total']['meta']['detector']['num_out']
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', helpers.golden_names('object'))
+def test_object_level_api_matches_reference(name):
+    """get_element objects: source.generate_rays(), optic.trace_global(rays) on a caller-modified ray array,
+    optic.make_image(rays); the global np.random stream ends where the reference's does."""
+    import xicsrt_amd
+    cfg, gold = helpers.load_golden(name)
+    np.random.seed(cfg['general']['random_seed'])
+    source = xicsrt_amd.get_element(cfg, 'source')
+    crystal = xicsrt_amd.get_element(cfg, 'crystal')
+    rays = source.generate_rays()
+    rays['mask'][::5] = False
+    assert np.array_equal(rays['mask'], gold['in/mask'])
+    assert np.allclose(rays['direction'], gold['in/direction'], rtol=FLOAT_RTOL, atol=1e-16)
+    rays = crystal.trace_global(rays)
+    assert np.array_equal(rays['mask'], gold['out/mask'])
+    for key in ('origin', 'direction', 'wavelength'):
+        g, h = gold['out/' + key], np.asarray(rays[key])
+        assert np.array_equal(np.isnan(h), np.isnan(g)), key
+        ok = ~np.isnan(g)
+        assert np.max(np.abs(h[ok] - g[ok])) <= FLOAT_RTOL * np.max(np.abs(g[ok])), key
+    image = crystal.make_image(rays)
+    assert image.dtype == np.float64 and np.array_equal(image, gold['image'])
+    assert np.random.random_sample() == float(gold['next_double'])

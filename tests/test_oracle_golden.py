@@ -61,3 +61,37 @@ def test_counts_against_reference(name, oracle):
         assert int(num_out[k]) == int(gold['num_out/' + nm]), nm
     for nm, img in helpers.split_images(flat, images).items():
         assert np.array_equal(img, gold['image/' + nm]), 'image ' + nm
+
+
+def _object_rays(gold, prefix):
+    rays = np.empty((8, len(gold[prefix + '/mask'])))
+    rays[0:3] = gold[prefix + '/origin'].T
+    rays[3:6] = gold[prefix + '/direction'].T
+    rays[6] = gold[prefix + '/wavelength']
+    rays[7] = 1.0
+    return np.ascontiguousarray(rays), np.ascontiguousarray(gold[prefix + '/mask'].astype(np.uint8))
+
+
+@pytest.mark.parametrize('name', _cases('object'))
+def test_object_level_tracing_against_reference(name, oracle):
+    """source.generate_rays(), caller switches rays off, optic.trace_global(rays), optic.make_image(rays)."""
+    cfg, gold = helpers.load_golden(name)
+    config, elements, flat = helpers.build(cfg)
+    state = helpers.seed_state(config['general']['random_seed'])
+    src_only = helpers.xscene.FlatScene(elements.source, [], ['source'])
+    num_out, images, rays, mask, st1 = helpers.oracle_history(src_only, state)
+    assert np.allclose(rays[0, 0:3].T, gold['in/origin'], rtol=0, atol=1e-15)
+    assert np.allclose(rays[0, 3:6].T, gold['in/direction'], rtol=1e-13, atol=1e-16)
+    ext_rays, ext_mask = _object_rays(gold, 'in')
+    ext = helpers.xscene.FlatScene(helpers.xscene.ExternalRays(ext_rays, ext_mask), [elements.optics[0]], ['source', 'crystal'])
+    num_out, images, rays, mask, st2 = helpers.oracle_history(ext, st1, all_rays=True)
+    assert int(num_out[0]) == int(gold['in/mask'].sum()) and int(num_out[1]) == int(gold['out/mask'].sum())
+    hist = helpers.xrt._history_from_device(['source', 'crystal'], rays, mask, ext.optic_objs)['crystal']
+    assert np.array_equal(hist['mask'], gold['out/mask'])
+    for key in ('origin', 'direction', 'wavelength'):
+        g, h = gold['out/' + key], hist[key]
+        assert np.array_equal(np.isnan(h), np.isnan(g)), key
+        ok = ~np.isnan(g)
+        assert np.max(np.abs(h[ok] - g[ok])) <= 1e-12 * np.max(np.abs(g[ok])), key
+    assert np.array_equal(helpers.split_images(ext, images)['crystal'], gold['image'])
+    assert helpers.state_next_double(st2) == float(gold['next_double'])

@@ -88,6 +88,8 @@ struct KSource {
     double  pois[7];            // sqrt(lam), log(lam), b, a, invalpha, vr, exp(-lam) (numpy's own libm expressions)
     int32_t use_poisson, pad2;
     const KPlasma* plasma;      // device; per-bundle model or null
+    const double*  ext_rays;    // XRT_SRC_EXTERNAL: [8][n_rays] device
+    const uint8_t* ext_mask;
 };
 
 struct KMesh {               // device pointers, see xrt_mesh_t
@@ -1581,7 +1583,9 @@ extern "C" int xrt_scene_check(const xrt_scene_t* sc)
         return fail(-2, "%s", "unknown angular_dist");
     if (s.wavelength_dist < XRT_WL_CONST || s.wavelength_dist > XRT_WL_VOIGT)
         return fail(-2, "%s", "unknown wavelength_dist");
-    if (s.kind < XRT_SRC_GENERIC || s.kind > XRT_SRC_PLASMA) return fail(-2, "%s", "unknown source kind");
+    if (s.kind < XRT_SRC_GENERIC || s.kind > XRT_SRC_EXTERNAL) return fail(-2, "%s", "unknown source kind");
+    if (s.kind == XRT_SRC_EXTERNAL && s.intensity > 0 && (!s.ext_rays || !s.ext_mask))
+        return fail(-2, "%s", "external rays missing");
     if (s.kind == XRT_SRC_PLASMA) {
         if (s.bundle_count < 1) return fail(-2, "%s", "plasma bundle_count < 1");
         if (s.spatial_dist != XRT_SPATIAL_UNIFORM || s.angular_dist != XRT_ANG_ISOTROPIC)
@@ -1645,7 +1649,7 @@ static size_t ws_off_polys(const xrt_scene_t* sc, int n_runs)
 static bool needs_staged(const xrt_scene_t* sc)
 {
     const xrt_source_t& s = sc->source;
-    if (s.kind == XRT_SRC_PLASMA) return true;
+    if (s.kind == XRT_SRC_PLASMA || s.kind == XRT_SRC_EXTERNAL) return true;
     if (s.spatial_dist == XRT_SPATIAL_GAUSSIAN || s.angular_dist == XRT_ANG_ISOTROPIC_XY || s.wavelength_dist == XRT_WL_NORMAL)
         return true;
     int n_bragg = 0;
@@ -1747,6 +1751,7 @@ static void build_kscene(const xrt_scene_t* sc, char* ws, KScene* k)
     d.bundle_count = s.bundle_count;
     d.bundle_intensity = s.bundle_intensity;
     d.use_poisson = s.use_poisson;
+    d.ext_rays = s.ext_rays; d.ext_mask = s.ext_mask;
     for (int i = 0; i < 3; i++) {
         const double low = -1.0 * s.plasma_size[i] / 2.0, high = s.plasma_size[i] / 2.0;
         d.plasma_low[i] = low; d.plasma_range[i] = high - low;
@@ -2008,16 +2013,18 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
             HIP_TRY(hipEventCreate(&timing_ev[ti][1]));
             HIP_TRY(hipEventRecord(timing_ev[ti][0], stream));
         }
-        const bool plasma = sc->source.kind == XRT_SRC_PLASMA;
+        const int src = sc->source.kind == XRT_SRC_PLASMA ? 1 : (sc->source.kind == XRT_SRC_EXTERNAL ? 2 : 0);
         bool special = false;
         for (int e = 0; e < sc->n_optics; e++)
             special = special || sc->optics[e].interact == XRT_INTERACT_MOSAIC || sc->optics[e].shape == XRT_SHAPE_MESH ||
                       (sc->optics[e].flags & XRT_F_TRACE_LOCAL);
         void (*kern)(const KScene, const KArgs, const KStaged);
-        if (hist) kern = plasma ? (special ? xrt_staged_kernel<true, true, true> : xrt_staged_kernel<true, true, false>)
-                                : (special ? xrt_staged_kernel<true, false, true> : xrt_staged_kernel<true, false, false>);
-        else      kern = plasma ? (special ? xrt_staged_kernel<false, true, true> : xrt_staged_kernel<false, true, false>)
-                                : (special ? xrt_staged_kernel<false, false, true> : xrt_staged_kernel<false, false, false>);
+        if (src == 2 && !hist) return fail(-2, "%s", "external rays are traced through xrt_trace_history");
+        if (hist) kern = src == 2 ? (special ? xrt_staged_kernel<true, 2, true> : xrt_staged_kernel<true, 2, false>)
+                       : src == 1 ? (special ? xrt_staged_kernel<true, 1, true> : xrt_staged_kernel<true, 1, false>)
+                                  : (special ? xrt_staged_kernel<true, 0, true> : xrt_staged_kernel<true, 0, false>);
+        else      kern = src == 1 ? (special ? xrt_staged_kernel<false, 1, true> : xrt_staged_kernel<false, 1, false>)
+                                  : (special ? xrt_staged_kernel<false, 0, true> : xrt_staged_kernel<false, 0, false>);
         hipLaunchKernelGGL(kern, dim3(slots), dim3(XRT_TILE), lds, stream, ks, a, g);
         HIP_TRY(hipGetLastError());
         if (ti >= 0) HIP_TRY(hipEventRecord(timing_ev[ti][1], stream));
@@ -2151,6 +2158,35 @@ extern "C" int xrt_trace_history(const xrt_scene_t* sc, const xrt_rng_state_t* s
                            reinterpret_cast<KState*>(state_out));
         HIP_TRY(hipGetLastError());
     }
+    return 0;
+}
+
+__global__ void xrt_image_kernel(const KOptic op, int64_t n, const double* rays, const uint8_t* mask, unsigned long long* images)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !mask[i]) return;
+    V3 X;
+    X.x = rays[0 * n + i]; X.y = rays[1 * n + i]; X.z = rays[2 * n + i];
+    image_hit(op, X, images);
+}
+
+extern "C" int xrt_make_image(const xrt_optic_t* optic, int64_t n, const double* rays, const uint8_t* mask,
+                              uint64_t* images, void* stream_)
+{
+    if (!optic || !images || (n > 0 && (!rays || !mask))) return fail(-1, "%s", "NULL argument");
+    if (!(optic->flags & XRT_F_IMAGE) || optic->pixel_nx <= 0 || optic->pixel_ny <= 0) return fail(-2, "%s", "optic makes no image");
+    if (n <= 0) return 0;
+    KOptic q;
+    memset(&q, 0, sizeof(q));
+    for (int i = 0; i < 3; i++) q.origin[i] = optic->origin[i];
+    for (int i = 0; i < 9; i++) q.R[i] = optic->orientation[i];
+    q.flags = optic->flags;
+    q.pixel_size = optic->pixel_size; q.pixel_xoff = optic->pixel_xoff; q.pixel_yoff = optic->pixel_yoff;
+    q.pixel_nx = optic->pixel_nx; q.pixel_ny = optic->pixel_ny; q.image_offset = optic->image_offset;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    hipLaunchKernelGGL(xrt_image_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, q, n, rays, mask,
+                       reinterpret_cast<unsigned long long*>(images));
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 

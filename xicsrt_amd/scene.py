@@ -20,13 +20,13 @@ import ctypes as C
 
 import numpy as np
 
-XRT_ABI_VERSION = 10
+XRT_ABI_VERSION = 11
 XRT_MAX_BUNDLE_FILTERS = 4
 XRT_MAX_OPTICS = 16
 XRT_MAX_APERTURES = 8
 XRT_HIST_COMPONENTS = 8
 
-SRC_KIND = {'zaxis': 0, 'direction': 1, 'target': 2, 'plasma': 3}
+SRC_KIND = {'zaxis': 0, 'direction': 1, 'target': 2, 'plasma': 3, 'external': 4}
 SPATIAL = {'uniform': 0, 'gaussian': 1}
 ANGULAR = {'isotropic': 0, 'isotropic_xy': 1, 'flat': 2, 'flat_xy': 3}
 WL_CONST, WL_UNIFORM, WL_NORMAL, WL_VOIGT = 0, 1, 2, 3
@@ -79,7 +79,8 @@ class Source(C.Structure):
                 ('voigt_cdf', C.POINTER(C.c_double)), ('voigt_x', C.POINTER(C.c_double)),
                 ('bundle_count', C.c_int64), ('plasma_size', C.c_double * 3),
                 ('bundle_intensity', C.c_double), ('use_poisson', C.c_int32), ('pad_plasma', C.c_int32),
-                ('plasma', C.POINTER(Plasma))]
+                ('plasma', C.POINTER(Plasma)),
+                ('ext_rays', C.c_void_p), ('ext_mask', C.c_void_p)]
 
 
 _PD, _PI, _PB = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
@@ -327,8 +328,35 @@ def plasma_as_source_param(obj, keep):
     return q, B, float(intensity), pl
 
 
+class ExternalRays:
+    """Stands in for the source when a caller's own ray array is traced (TraceObject.trace_global(rays)):
+    `rays` [8, n] float64 and `mask` [n] uint8 are device tensors kept alive by this object."""
+
+    cone_axis_rule = 'external'
+
+    def __init__(self, rays, mask):
+        self.rays, self.mask = rays, mask
+        self.n = int(mask.shape[0])
+
+    @staticmethod
+    def address(x):
+        return x.data_ptr() if hasattr(x, 'data_ptr') else x.ctypes.data
+
+
 def flatten_source(obj, out, keep):
     """Fill a Source struct from an initialised XicsrtSource* object; `keep` pins host arrays."""
+    out.ext_rays = None
+    out.ext_mask = None
+    if obj.cone_axis_rule == 'external':
+        C.memset(C.byref(out), 0, C.sizeof(out))
+        out.kind = SRC_KIND['external']
+        out.intensity = obj.n
+        _vec(out.orientation, np.eye(3))
+        out.two_pi = float(2 * np.pi)
+        out.ext_rays = obj.address(obj.rays)
+        out.ext_mask = obj.address(obj.mask)
+        keep.append(obj)
+        return
     p = obj.param
     out.bundle_count = 0
     _vec(out.plasma_size, np.zeros(3))
@@ -640,6 +668,7 @@ class FlatScene:
         self.struct = Scene()
         self._keep = []
         self.names = list(names)                    # source name then optic names
+        self.optic_objs = list(optic_objs)
         flatten_source(source_obj, self.struct.source, self._keep)
         self.struct.n_optics = len(optic_objs)
         offset = 0

@@ -249,10 +249,11 @@ class DeviceTrace:
                                 ws.data_ptr(), need, stream)
         self.capi.check(st, 'xrt_trace')
 
-    def trace_history(self, state, keep_images=True):
+    def trace_history(self, state, keep_images=True, all_rays=False):
         """
         One iteration from an explicit MT19937 state (key, pos, has_gauss, gauss).
         Returns (rays[n_el, 8, N] float64, mask[n_el, N] bool, state_out) on the host.
+        `all_rays`: keep rays whose source mask is off (caller-supplied ray arrays).
         """
         t = self.torch
         n, ne = self.flat.n_rays, self.flat.n_elements
@@ -275,7 +276,8 @@ class DeviceTrace:
         out = xscene.RngState.from_buffer_copy(st_out.cpu().numpy().tobytes())
         state_out = (np.ctypeslib.as_array(out.key).copy(), int(out.pos), int(out.has_gauss), float(out.gauss))
         mask_h = mask.cpu().numpy()[:, :n].astype(bool)
-        n = int(mask_h[0].sum())        # plasma sources: the ray count is drawn, n_rays is the capacity
+        if not all_rays:
+            n = int(mask_h[0].sum())    # plasma sources: the ray count is drawn, n_rays is the capacity
         return rays.cpu().numpy()[:, :, :n], mask_h[:, :n], state_out
 
     def results(self):
@@ -312,13 +314,16 @@ def _empty_output(config):
             'lost': {'meta': {}, 'history': {}}}
 
 
-def _history_from_device(names, rays, mask):
+def _history_from_device(names, rays, mask, optics=None):
     """
     Per-element ray dictionaries in original ray order from the device snapshot.
     Rays that died at an element carry the intersection point they died at
     (or NaN), later elements see NaN origins and the unchanged direction, as
     the reference's masked NumPy updates leave them (optics/_ShapeObject.py:76-79,
-    _InteractObject.py:36-39).
+    _InteractObject.py:36-39).  An optic traced in its local frame (`optics[e-1]`
+    with trace_local) rotates EVERY ray there and back, dead ones included
+    (optics/_TraceObject.py:146-154), which perturbs their directions when the
+    orientation matrix is not exactly orthonormal; that round trip is replayed here.
     """
     history = {}
     n = mask.shape[1]
@@ -335,6 +340,10 @@ def _history_from_device(names, rays, mask):
             origin[dead_before] = np.nan
             direction[dead_before] = prev_dir[dead_before]
             wavelength[dead_before] = prev_wl[dead_before]
+            obj = optics[e - 1] if optics is not None and e - 1 < len(optics) else None
+            if obj is not None and obj.param.get('trace_local') and dead_before.any():
+                d = np.ascontiguousarray(direction[dead_before])
+                direction[dead_before] = obj.vector_to_external(obj.vector_to_local(d))
         history[name] = RayArray({'origin': origin, 'direction': direction,
                                   'wavelength': wavelength, 'mask': m})
         if e == 0:
@@ -455,7 +464,7 @@ def _run_with_history(config, elements, device, seed, max_lost_iter):
         st = rng.get_state()
         rays, mask, state_out = device.trace_history((st[1], st[2], st[3], st[4]), general['keep_images'])
         _advance(rng, state_out)
-        history = _history_from_device(elements.names, rays, mask)
+        history = _history_from_device(elements.names, rays, mask, elements.optics)
         found, lost = _sort_history(history, rng, max_lost_iter)
         single = _empty_output(config)
         # totals are accumulated on the device and filled in by the caller
@@ -642,11 +651,52 @@ def generate_rays_from_global_state(source_obj):
     return out
 
 
+def _rays_to_device(rays):
+    """RayArray / dict of (n,3),(n,3),(n,),(n,) arrays -> device tensors [8, n] float64 and [n] uint8."""
+    t = _torch()
+    n = len(rays['mask'])
+    host = np.empty((xscene.XRT_HIST_COMPONENTS, n), dtype=np.float64)
+    host[0:3] = np.asarray(rays['origin'], dtype=np.float64).T
+    host[3:6] = np.asarray(rays['direction'], dtype=np.float64).T
+    host[6] = np.asarray(rays['wavelength'], dtype=np.float64)
+    host[7] = np.asarray(rays['weight'], dtype=np.float64) if 'weight' in rays else 1.0
+    dev = t.device('cuda', t.cuda.current_device())
+    d_rays = t.from_numpy(host).to(dev)
+    d_mask = t.from_numpy(np.ascontiguousarray(np.asarray(rays['mask']), dtype=np.uint8)).to(dev)
+    return d_rays, d_mask
+
+
 def trace_optic_object(optic_obj, rays):
-    raise NotImplementedError('tracing externally supplied ray arrays through a single optic '
-                              'is not implemented on the device path yet; use raytrace(config).')
+    """
+    XicsrtOptic*.trace_global(rays) on a caller's ray array (optics/_TraceObject.py:135-178): the rays
+    are updated in place and returned, like the reference's masked NumPy updates leave them (dead rays
+    get a NaN origin or the point they died at; directions change only for reflected rays).  A Bragg
+    test draws from the global legacy np.random stream, which is advanced accordingly.
+    """
+    d_rays, d_mask = _rays_to_device(rays)
+    flat = xscene.FlatScene(xscene.ExternalRays(d_rays, d_mask), [optic_obj], ['rays', 'optic'])
+    device = DeviceTrace(flat)
+    out, mask, state_out = device.trace_history(_global_state(), keep_images=False, all_rays=True)
+    _set_global_state(state_out)
+    history = _history_from_device(['rays', 'optic'], out, mask, [optic_obj])
+    after = history['optic']
+    rays['origin'][:] = after['origin']
+    rays['direction'][:] = after['direction']
+    rays['mask'][:] = after['mask']
+    return rays
 
 
 def image_of_optic_object(optic_obj, rays):
-    raise NotImplementedError('make_image on externally supplied ray arrays is not implemented '
-                              'on the device path yet; images are produced by raytrace(config).')
+    """XicsrtOptic*.make_image(rays) (optics/_TraceObject.py:234-293): float64 (nx, ny) counts or None."""
+    if not optic_obj.param['enable_image']:
+        return None
+    t = _torch()
+    from . import capi
+    d_rays, d_mask = _rays_to_device(rays)
+    flat = xscene.FlatScene(xscene.ExternalRays(d_rays, d_mask), [optic_obj], ['rays', 'optic'])
+    o = flat.struct.optics[0]
+    images = t.zeros(max(flat.image_bins, 1), dtype=t.int64, device=d_rays.device)
+    capi.check(capi.lib().xrt_make_image(C.byref(o), len(rays['mask']), d_rays.data_ptr(), d_mask.data_ptr(),
+                                         images.data_ptr(), t.cuda.current_stream().cuda_stream), 'xrt_make_image')
+    t.cuda.current_stream().synchronize()
+    return images.cpu().numpy()[:o.pixel_nx * o.pixel_ny].reshape(o.pixel_nx, o.pixel_ny).astype(np.float64)
