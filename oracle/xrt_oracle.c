@@ -1041,7 +1041,9 @@ static inline double rocking_p(const xrt_optic_t* op, double inc, double bragg)
 /* optics/_InteractMosaicCrystal.py:53-139.  On entry r->mask = rays on the optic (after bounds),
  * r->nrm = nominal normals.  Reflected rays get their new direction here; mask becomes the
  * reflected set. */
-static void interact_mosaic(const xrt_optic_t* op, rays_t* r, mt_t* mt)
+/* returns 0 when no ray is left after the cut-off: the reference then skips the whole block,
+ * including the O[:] = xloc update of reflect_vectors (:78 `if np.sum(m) > 0`) */
+static int interact_mosaic(const xrt_optic_t* op, rays_t* r, mt_t* mt)
 {
     const int64_t n = r->n;
     if (op->mosaic_has_cutoff) {
@@ -1054,7 +1056,7 @@ static void interact_mosaic(const xrt_optic_t* op, rays_t* r, mt_t* mt)
     }
     int64_t alive = 0;
     for (int64_t i = 0; i < n; i++) alive += r->mask[i];
-    if (alive == 0) return;
+    if (alive == 0) return 0;
     uint8_t* refl = calloc((size_t)n, 1);
     double* nm = malloc(sizeof(double) * 3 * (size_t)n);
     const double* A = op->mosaic_A;
@@ -1105,6 +1107,7 @@ static void interact_mosaic(const xrt_optic_t* op, rays_t* r, mt_t* mt)
     }
     for (int64_t i = 0; i < n; i++) r->mask[i] = r->mask[i] && refl[i];
     free(refl); free(nm);
+    return 1;
 }
 
 /* optics/_InteractCrystal.py:96-196: Bragg test, draws in original ray order */
@@ -1157,9 +1160,10 @@ static void trace_optic(const xrt_optic_t* op, rays_t* r, mt_t* mt)
     check_bounds(op, r);
     if (op->interact == XRT_INTERACT_CRYSTAL && (op->flags & XRT_F_CHECK_BRAGG))
         angle_check(op, r, mt);
+    int touched = 1;
     if (op->interact == XRT_INTERACT_MOSAIC)
-        interact_mosaic(op, r, mt);
-    for (int64_t i = 0; i < r->n; i++) {
+        touched = interact_mosaic(op, r, mt);
+    for (int64_t i = 0; touched && i < r->n; i++) {
         /* InteractObject.interact / InteractMirror.reflect_vectors (_InteractMirror.py:29-42):
          * O[:] = xloc for every ray (NaN where there was no intersection) */
         double* o = &r->o[3 * i];
@@ -1176,6 +1180,11 @@ static void trace_optic(const xrt_optic_t* op, rays_t* r, mt_t* mt)
             for (int k = 0; k < 3; k++) d[k] = d[k] - 2.0 * (dt * nn[k]);
         }
     }
+    /* Upstream quirk kept for parity: ShapeMesh.intersect returns a fresh mask array and
+     * InteractMosaicCrystal.interact never stores its result into rays['mask'] (plane and sphere
+     * shapes only appear to, because their intersect aliases rays['mask']); a mesh mosaic crystal
+     * therefore leaves every incoming ray "alive", with a NaN or on-surface origin. */
+    if (op->interact == XRT_INTERACT_MOSAIC && op->shape == XRT_SHAPE_MESH) memcpy(r->mask, r->prev, (size_t)r->n);
     if (local) {    /* ray_to_external (_GeometryObject.py:113-124) */
         for (int64_t i = 0; i < r->n; i++) {
             double t[3];

@@ -281,6 +281,27 @@ def build_cases():
     c = _crystal('XicsrtOpticSphericalMosaicCrystal', radius=1.0, check_bragg=False, **mos)
     add('M_spherical_mosaic_nobragg_trace', 'trace', cfg_three(500, c, history=True, seed=93))
 
+    c = _crystal('XicsrtOpticPlanarMosaicCrystal', trace_local=True, mosaic_cutoff=1e-2, **mos)
+    add('M_planar_mosaic_local_trace', 'trace', cfg_three(2000, c, history=True, seed=94))
+    # a user-supplied mesh (a patch of a sphere of radius 1.2 in the optic's frame) with mosaic interaction
+    gx, gy = np.meshgrid(np.linspace(-0.11, 0.11, 9), np.linspace(-0.11, 0.11, 8), indexing='ij')
+    gz = 1.2 - np.sqrt(1.2 ** 2 - gx ** 2 - gy ** 2)
+    pts = np.stack((gx.ravel(), gy.ravel(), gz.ravel())).T
+    nrm = (np.array([0.0, 0.0, 1.2]) - pts) / 1.2
+    for interp in (False, True):
+        c = _crystal('XicsrtOpticMeshMosaicCrystal', mesh_points=pts.tolist(), mesh_normals=nrm.tolist(),
+                     mesh_interpolate=interp, trace_local=True, **mos)
+        add('M_mesh_mosaic_%s_trace' % ('interp' if interp else 'flat'), 'trace',
+            cfg_three(1500, c, history=True, seed=95 + int(interp)))
+    c = _crystal('XicsrtOpticMeshMosaicCrystal', mesh_points=pts.tolist(), mesh_normals=nrm.tolist(),
+                 mesh_interpolate=True, mosaic_cutoff=1e-3, trace_local=True, **mos)
+    add('M_mesh_mosaic_counts', 'counts', cfg_three(20000, c, seed=97, runs=2, iters=2))
+    # the same mesh read in global coordinates (trace_local False): nothing lands inside the bounds,
+    # and the mosaic interaction then leaves every ray untouched
+    c = _crystal('XicsrtOpticMeshMosaicCrystal', mesh_points=pts.tolist(), mesh_normals=nrm.tolist(),
+                 mesh_interpolate=False, **mos)
+    add('M_mesh_mosaic_global_trace', 'trace', cfg_three(600, c, history=True, seed=98))
+
     # --- full results dictionary with histories (found / shuffled lost sample) ---
     cfg = cfg_three(3000, dict(sph, rocking_fwhm=2e-3), seed=81, runs=2, iters=2, history=True)
     cfg['general']['history_max_lost'] = 200

@@ -65,8 +65,7 @@ def test_strict_config_check_and_merge():
     assert merged['general']['keep_history'] is False and merged['extra_section'] == {'a': 1}
     with pytest.raises(Exception, match='Could not find XicsrtOpticNope'):
         xrt.find_class('XicsrtOpticNope', 'optics', [])
-    with pytest.raises(NotImplementedError):
-        xrt.find_class('XicsrtOpticMeshMosaicCrystal', 'optics', [])
+    assert xrt.find_class('XicsrtOpticMeshMosaicCrystal', 'optics', []).interact_kind == 'mosaic'
     with pytest.raises(ValueError, match='intensity of less than one'):
         xicsrt_amd.get_element({'sources': {'s': {'class_name': 'XicsrtSourceGeneric'}}}, 's')
 
@@ -151,14 +150,10 @@ def test_unsupported_scenes_fail_loudly():
     """No CPU fallback: features outside the device path are refused (class lookup or xrt_scene_check)."""
     L = capi.lib()
     cfg, gold = helpers.load_golden('M_planar_mosaic_trace')
-    cfg['optics']['crystal']['trace_local'] = True
+    cfg['sources']['source']['intensity'] = 2 ** 29
     config, elements, flat = helpers.build(cfg)
     assert L.xrt_scene_check(flat.byref()) != 0
-    assert b'trace_local' in L.xrt_last_error()
-    cfg, gold = helpers.load_golden('E_mesh_flat_trace')
-    cfg['optics']['crystal']['class_name'] = 'XicsrtOpticMeshMosaicCrystal'
-    with pytest.raises(NotImplementedError):
-        helpers.build(cfg)
+    assert b'2^29' in L.xrt_last_error()
     cfg, gold = helpers.load_golden('F_datafile_trace')
     cfg['sources']['source'].update(linewidth=1e13)         # one Voigt table per bundle would be needed
     with pytest.raises(NotImplementedError):
@@ -177,7 +172,7 @@ def test_supported_scenes_validate():
                  'W_normal_trace', 'S_gaussian_spatial_trace', 'G_isotropic_xy_trace', 'Q_four_trace',
                  'P_local_trace', 'M_spherical_mosaic_cutoff_trace', 'F_plasma_trace', 'D_ToroidalCrystal_trace',
                  'E_mesh_flat_trace', 'E_mesh_interp_trace', 'E_mesh_sphere_trace', 'E_mesh_cylinder_trace',
-                 'F_toroidal_trace', 'F_datafile_filter_trace', 'F_spread_radius_trace', 'F_generic_plasma_trace'):
+                 'M_mesh_mosaic_interp_trace', 'M_planar_mosaic_local_trace', 'F_toroidal_trace', 'F_datafile_filter_trace', 'F_spread_radius_trace', 'F_generic_plasma_trace'):
         cfg, gold = helpers.load_golden(name)
         config, elements, flat = helpers.build(cfg)
         assert L.xrt_scene_check(flat.byref()) == 0, (name, L.xrt_last_error())

@@ -1603,7 +1603,7 @@ extern "C" int xrt_scene_check(const xrt_scene_t* sc)
             if (!m || m->n_points < 3 || m->n_faces < 1 || !m->points || !m->p0 || !m->faces_normal || !m->p_faces_idx)
                 return fail(-2, "%s", "mesh tables missing");
             if (m->interpolate && (m->n_simplices < 1 || !m->ct_simplices || !m->ct_grad)) return fail(-2, "%s", "mesh interpolation tables missing");
-            if (o.interact == XRT_INTERACT_MOSAIC) return fail(-3, "%s", "mesh mosaic crystals are not implemented on the device path");
+
         }
         if (o.shape == XRT_SHAPE_TORUS && (o.torus_root < 0 || o.torus_root > 3))
             return fail(-2, "%s", "torus root index out of range");
@@ -1611,8 +1611,8 @@ extern "C" int xrt_scene_check(const xrt_scene_t* sc)
             return fail(-3, "%s", "optic interaction is not implemented on the device path");
         if (o.interact == XRT_INTERACT_MOSAIC && (o.mosaic_depth < 0 || o.mosaic_depth > 1000))
             return fail(-2, "%s", "mosaic_depth out of range");
-        if (o.interact == XRT_INTERACT_MOSAIC && (o.flags & XRT_F_TRACE_LOCAL))
-            return fail(-3, "%s", "mosaic crystals with trace_local are not implemented on the device path");
+        if (o.interact == XRT_INTERACT_MOSAIC && sc->source.intensity >= (1ll << 29))
+            return fail(-2, "%s", "mosaic crystals take at most 2^29 - 1 rays per iteration (three ray-index bits carry flags)");
         if (o.n_apertures < 0 || o.n_apertures > XRT_MAX_APERTURES) return fail(-2, "%s", "bad aperture count");
         if ((o.flags & XRT_F_IMAGE) && (o.pixel_nx <= 0 || o.pixel_ny <= 0 || o.image_offset < 0 ||
                                         o.image_offset + (int64_t)o.pixel_nx * o.pixel_ny > sc->image_bins))
@@ -1695,7 +1695,7 @@ static size_t staged_bytes(const xrt_scene_t* sc, int n_runs)
     if (!needs_staged(sc)) return 0;
     const size_t n = (size_t)(sc->source.intensity > 0 ? sc->source.intensity : 1);
     const size_t nb = (size_t)(sc->source.bundle_count > 0 ? sc->source.bundle_count : 0);
-    return al256((size_t)staged_slots(n_runs) * (n * (XRT_ST_ARRAYS * sizeof(double) + sizeof(uint32_t)) + nb * XRT_ST_BUNDLE_ROWS * sizeof(double)) + 256);
+    return al256((size_t)staged_slots(n_runs) * (n * (XRT_ST_ARRAYS * sizeof(double) + 2 * sizeof(uint32_t)) + nb * XRT_ST_BUNDLE_ROWS * sizeof(double)) + 256);
 }
 
 extern "C" size_t xrt_workspace_bytes(const xrt_scene_t* sc, int32_t n_runs)
@@ -1997,7 +1997,8 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
         char* base = ws + ws_off_staged(sc, n_runs);
         g.arr = reinterpret_cast<double*>(base);
         g.ids = reinterpret_cast<uint32_t*>(base + (size_t)slots * (size_t)N * XRT_ST_ARRAYS * sizeof(double));
-        g.bundle_off = reinterpret_cast<double*>(base + (size_t)slots * (size_t)N * (XRT_ST_ARRAYS * sizeof(double) + sizeof(uint32_t)));
+        g.aux = g.ids + (size_t)slots * (size_t)N;
+        g.bundle_off = reinterpret_cast<double*>(base + (size_t)slots * (size_t)N * (XRT_ST_ARRAYS * sizeof(double) + 2 * sizeof(uint32_t)));
         g.flags = reinterpret_cast<uint32_t*>(ws) + 16;        // status word in the 256-byte workspace header
         g.gauss_state = reinterpret_cast<KState*>(ws + ws_off_gauss(sc, n_runs));
         for (int i = 0; i < 9; i++) g.spatial_A[i] = sc->source.spatial_A[i];

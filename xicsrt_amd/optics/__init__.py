@@ -236,6 +236,7 @@ _ELEMENTS = _ELEMENTS + (
     ('XicsrtOpticMeshSphericalCrystal', InteractCrystal, ShapeMeshSphere),
     ('XicsrtOpticMeshCylindricalCrystal', InteractCrystal, ShapeMeshCylinder),
     ('XicsrtOpticMeshToroidalCrystal', InteractCrystal, ShapeMeshTorus),
+    ('XicsrtOpticMeshMosaicCrystal', InteractMosaicCrystal, ShapeMesh),
 )
 
 BUILTIN = {}
@@ -248,6 +249,4 @@ for _name, _interact, _shape in _ELEMENTS:
 del _name, _interact, _shape, _cls
 
 # Known reference element classes that the device path does not implement yet.
-NOT_IMPLEMENTED = (
-    'XicsrtOpticMeshMosaicCrystal',
-)
+NOT_IMPLEMENTED = ()
