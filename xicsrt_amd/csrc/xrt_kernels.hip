@@ -1659,8 +1659,18 @@ static bool needs_staged(const xrt_scene_t* sc)
     }
     return n_bragg > 1;
 }
-#define XRT_ST_SLOTS 128
-static int staged_slots(int n_runs) { return n_runs < XRT_ST_SLOTS ? (n_runs < 1 ? 1 : n_runs) : XRT_ST_SLOTS; }
+// Staged path: one workgroup per slot, one per CU (XRT_ST_SLOTS = 256 CUs), fewer when the per-slot
+// ray arrays of a scene would take more than XRT_ST_BUDGET bytes of workspace in total.
+#define XRT_ST_SLOTS 256
+#define XRT_ST_BUDGET (64ull << 30)
+static int staged_slots_for(int n_runs, size_t per_slot_bytes)
+{
+    size_t s = XRT_ST_SLOTS;
+    if (per_slot_bytes > 0 && s * per_slot_bytes > XRT_ST_BUDGET) s = XRT_ST_BUDGET / per_slot_bytes;
+    if (s < 1) s = 1;
+    if ((size_t)n_runs < s) s = (size_t)(n_runs < 1 ? 1 : n_runs);
+    return (int)s;
+}
 static size_t ws_off_gauss(const xrt_scene_t* sc, int n_runs) { return al256(ws_off_polys(sc, n_runs) + sizeof(uint32_t) * 624 * (XRT_MAX_HEADS + 1)); }
 static size_t ws_off_staged(const xrt_scene_t* sc, int n_runs) { return al256(ws_off_gauss(sc, n_runs) + sizeof(KState) * (size_t)n_runs); }
 // bytes of one mesh's tables on the device (each array 256-byte aligned) + its KMesh header
@@ -1690,12 +1700,17 @@ static size_t plasma_bytes(const xrt_scene_t* sc)
                                   + 2 * al256(sizeof(double) * (size_t)(P->n_temperature > 0 ? P->n_temperature : 1));
 }
 
+static size_t staged_slot_bytes(const xrt_scene_t* sc)
+{
+    const size_t n = (size_t)(sc->source.intensity > 0 ? sc->source.intensity : 1);
+    const size_t nb = (size_t)(sc->source.bundle_count > 0 ? sc->source.bundle_count : 0);
+    return n * (XRT_ST_ARRAYS * sizeof(double) + 2 * sizeof(uint32_t)) + nb * XRT_ST_BUNDLE_ROWS * sizeof(double);
+}
+static int staged_slots(const xrt_scene_t* sc, int n_runs) { return staged_slots_for(n_runs, staged_slot_bytes(sc)); }
 static size_t staged_bytes(const xrt_scene_t* sc, int n_runs)
 {
     if (!needs_staged(sc)) return 0;
-    const size_t n = (size_t)(sc->source.intensity > 0 ? sc->source.intensity : 1);
-    const size_t nb = (size_t)(sc->source.bundle_count > 0 ? sc->source.bundle_count : 0);
-    return al256((size_t)staged_slots(n_runs) * (n * (XRT_ST_ARRAYS * sizeof(double) + 2 * sizeof(uint32_t)) + nb * XRT_ST_BUNDLE_ROWS * sizeof(double)) + 256);
+    return al256((size_t)staged_slots(sc, n_runs) * staged_slot_bytes(sc) + 256);
 }
 
 extern "C" size_t xrt_workspace_bytes(const xrt_scene_t* sc, int32_t n_runs)
@@ -1993,7 +2008,7 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
         // general path: array-at-a-time passes with one sequential stream head per run
         KStaged g;
         memset(&g, 0, sizeof(g));
-        const int slots = staged_slots(n_runs);
+        const int slots = staged_slots(sc, n_runs);
         char* base = ws + ws_off_staged(sc, n_runs);
         g.arr = reinterpret_cast<double*>(base);
         g.ids = reinterpret_cast<uint32_t*>(base + (size_t)slots * (size_t)N * XRT_ST_ARRAYS * sizeof(double));
