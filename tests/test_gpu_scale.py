@@ -9,6 +9,8 @@ import numpy as np
 import pytest
 
 import helpers
+from xicsrt_amd import config as xconfig
+from xicsrt_amd import xicsrt_raytrace as xrt
 
 pytestmark = pytest.mark.gpu
 
@@ -158,3 +160,47 @@ def test_random_scenes_equal_oracle(case):
     rs2 = np.random.RandomState(0)
     rs2.set_state(('MT19937',) + tuple(st))
     assert rs2.random_sample() == helpers.state_next_double(o_st)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('segments', ['3', '7'])
+@pytest.mark.parametrize('name', ['C_sphere_runs_iters', 'B_mirror_runs', 'C_sphere_2e5_s3', 'D_ToroidalCrystal_1e5',
+                                  'E_mesh_interp_counts', 'A_example00_1e5', 'S_focused_1e5', 'W_voigt_1e5',
+                                  'P_aperture_1e5', 'D_PlanarCrystal_bragg_1e5', 'G_flat_xy_5e4'])
+def test_segmented_runs_equal_reference(name, segments, monkeypatch):
+    """Runs split into segments (one work unit each, count pass + propagate pass, chunked Bragg stream)
+    give the reference's integers: golden num_out and images, several iterations included."""
+    if name not in helpers.golden_names('counts'):
+        pytest.skip('no such golden')
+    monkeypatch.setenv('XICSRT_SEGMENTS', segments)
+    cfg, gold = helpers.load_golden(name)
+    config, elements, flat = helpers.build(cfg)
+    g = config['general']
+    seeds = xrt.run_seeds(g['random_seed'], g['number_of_runs'])
+    dev = xrt.DeviceTrace(flat)
+    dev.trace(seeds, g['number_of_iter'], keep_images=True)
+    meta, image = dev.results()
+    for nm in flat.names:
+        assert int(meta[nm]['num_out']) == int(gold['num_out/' + nm]), nm
+    for nm in flat.names[1:]:
+        if image[nm] is not None:
+            assert np.array_equal(image[nm].astype(np.int64), gold['image/' + nm]), nm
+
+
+@pytest.mark.gpu
+def test_few_long_runs_are_segmented_and_equal_the_oracle():
+    """3 runs x 3e6 rays x 2 iterations of the bench scene: the library segments them on its own;
+    counts and both images equal the oracle's, and the next iteration continues the right streams."""
+    import bench
+    config = xconfig.get_config(bench.spectrometer_config(3000000, 3, seed=21))
+    config['general']['number_of_iter'] = 2
+    elements = xrt.Elements(config)
+    flat = elements.flatten()
+    seeds = xrt.run_seeds(21, 3)
+    dev = xrt.DeviceTrace(flat)
+    dev.trace(seeds, 2, keep_images=True)
+    meta, image = dev.results()
+    o_num, o_img = helpers.oracle_counts(flat, seeds, 2, threads=3)
+    assert [int(meta[nm]['num_out']) for nm in flat.names] == [int(v) for v in o_num]
+    got = np.concatenate([image[nm].ravel() for nm in flat.names[1:]]).astype(np.int64)
+    assert np.array_equal(got, o_img[:flat.image_bins])

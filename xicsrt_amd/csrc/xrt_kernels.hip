@@ -1165,6 +1165,87 @@ void xrt_export_state_kernel(const KStream* in, const KState* orig, KState* out)
     }
 }
 
+// Jump-ahead for segmented runs: every run needs n_jobs positioned copies of its stream head
+// (source heads of every segment, the chunk heads of the Bragg stream, the stream head moved
+// behind the source arrays).  job j of a run: polynomial j (t^J mod phi, J = offset - 512 from the
+// canonical form) applied to the run's 19937+623-word stretch -> dst[run * n_jobs + j] at absolute
+// position next + offset; offset[j] < 512 (J <= 0): the head is the stream head itself.  The
+// workgroups of a run (gridDim.y of them) each rebuild the stretch and take every gridDim.y-th job.
+struct KJumpJobs {
+    const uint32_t* polys;      // [n_jobs][624] global
+    const uint64_t* offsets;    // [n_jobs] words from the stream head's `next`
+    KStream* dst;               // [n_runs][n_jobs]
+    int32_t n_jobs, n_runs;
+};
+
+__global__ __launch_bounds__(XRT_JUMP_THREADS)
+void xrt_jump_jobs_kernel(const KStream* streams, const KJumpJobs jobs)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t jlds[];
+    uint32_t* S = jlds;                         // [XRT_STRETCH]
+    const int tid = threadIdx.x;
+    for (int run = blockIdx.x; run < jobs.n_runs; run += gridDim.x) {
+        const KStream* st = streams + run;
+        const uint64_t gen = uni64(st->gen), next = uni64(st->next);
+        __syncthreads();
+        if (tid < 624) S[tid] = st->ring[((uint32_t)gen - 624u + (uint32_t)tid) & XRT_RMASK];
+        __syncthreads();
+        for (int base = 624; base < XRT_STRETCH; base += 227) {
+            int chunk = XRT_STRETCH - base;
+            if (chunk > 227) chunk = 227;
+            if (tid < chunk) {
+                const int n = base + tid;
+                S[n] = mt_mix(S[n - 624], S[n - 623], S[n - 227]);
+            }
+            __syncthreads();
+        }
+        for (int j = blockIdx.y; j < jobs.n_jobs; j += gridDim.y) {
+            KStream* out = jobs.dst + (size_t)run * jobs.n_jobs + j;
+            const uint64_t off = jobs.offsets[j];
+            const uint64_t target = next + off;
+            if (off < (uint64_t)XRT_AHEAD) {
+                if (tid < (int)XRT_RING) out->ring[tid] = st->ring[tid];
+                if (tid == 0) { out->gen = gen; out->next = target; }
+                continue;
+            }
+            const uint32_t* g = jobs.polys + (size_t)j * 624;
+            if (tid < 624) {
+                uint32_t acc = 0;
+                const uint32_t* sx = S + tid;
+                for (int b = 0; b < 624; b++) {
+                    uint32_t m = uni32(g[b]);
+                    const uint32_t* base = sx + 32 * b;
+                    while (__builtin_popcount(m) >= 4) {
+                        const int i0 = __builtin_ctz(m); m &= m - 1u;
+                        const int i1 = __builtin_ctz(m); m &= m - 1u;
+                        const int i2 = __builtin_ctz(m); m &= m - 1u;
+                        const int i3 = __builtin_ctz(m); m &= m - 1u;
+                        const uint32_t a0 = base[i0], a1 = base[i1], a2 = base[i2], a3 = base[i3];
+                        acc ^= (a0 ^ a1) ^ (a2 ^ a3);
+                    }
+                    while (m) {
+                        const int i = __builtin_ctz(m);
+                        m &= m - 1u;
+                        acc ^= base[i];
+                    }
+                }
+                out->ring[((uint32_t)target - 624u + (uint32_t)tid) & XRT_RMASK] = acc;
+            }
+            if (tid == 0) { out->gen = target; out->next = target; }
+        }
+    }
+}
+
+__global__ void xrt_copy_streams_kernel(KStream* dst, const KStream* src, int64_t src_stride, int n)
+{
+    // dst[r] = src[r * src_stride] (all 4128 bytes), one workgroup per stream
+    const int r = blockIdx.x;
+    if (r >= n) return;
+    const uint64_t* a = reinterpret_cast<const uint64_t*>(src + (size_t)r * src_stride);
+    uint64_t* b = reinterpret_cast<uint64_t*>(dst + r);
+    for (int i = threadIdx.x; i < (int)(sizeof(KStream) / 8); i += blockDim.x) b[i] = a[i];
+}
+
 // --------------------------------------------------------------------------
 // the propagation kernel
 // --------------------------------------------------------------------------
@@ -1178,6 +1259,15 @@ struct KArgs {
     uint32_t* run_counter;              // dynamic run dispenser
     double*  hist;                      // HIST only
     uint8_t* hmask;
+    // segmented runs (SEG kernels): a run's rays are split into n_seg segments of seg_len rays
+    // (a multiple of the tile), one work unit each; `heads` is then [n_runs][n_seg][n_src_heads].
+    int32_t  n_seg;
+    int32_t  mode;                      // 1: count the Bragg candidates of every unit; 2: propagate
+    int64_t  seg_len;
+    uint32_t* unit_count;               // [n_runs][n_seg] candidates per unit (written by mode 1)
+    const KStream* chunk_heads;         // per run n_seg stream heads, chunk_words apart, from the first Bragg uniform on
+    int64_t  chunk_words;
+    int64_t  run_stride;                // SEG: heads / chunk_heads of consecutive runs are this many KStreams apart
 };
 
 #ifndef XRT_WAVES_PER_EU
@@ -1188,12 +1278,17 @@ struct KArgs {
 // cone, shared cone axis, constant or uniform wavelength, plane/sphere, no
 // apertures) with lower register use; 1: every source / analytic shape /
 // aperture feature; 2: 1 + optics traced in their local frame and mesh optics.
-template <bool HIST, int VARIANT>
+// SEG: few runs of many rays -- the work unit is a segment of a run (see KArgs); the
+// Bragg uniform of a ray is indexed by its ordered live rank in the whole run, so a
+// first launch (mode 1) counts every unit's candidates and the second (mode 2) starts
+// each unit at the stream position the counts of the earlier segments give.
+template <bool HIST, int VARIANT, bool SEG>
 __global__ __launch_bounds__(XRT_TILE, (VARIANT == 2 ? 2 : XRT_WAVES_PER_EU))
 void xrt_trace_kernel(const KScene sc, const KArgs args)
 {
     constexpr bool FULL = VARIANT >= 1;
     constexpr bool EXT = VARIANT == 2;
+    static_assert(!(SEG && HIST), "history is kept by unsegmented runs");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     // One circular structure-of-arrays buffer of XRT_QCAP ray records serves as
     //  (a) the FIFO queue of rays waiting for the Bragg test (filled tile by tile in ray
@@ -1238,8 +1333,14 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
         // ---- next run ------------------------------------------------------
         if (tid == 0) bcast[0] = atomicAdd(args.run_counter, 1u);
         __syncthreads();
-        const uint32_t run = uni32(bcast[0]);
+        const uint32_t unit = uni32(bcast[0]);
+        uint32_t run = unit, seg = 0;
+        if (SEG) { run = unit / (uint32_t)args.n_seg; seg = unit - run * (uint32_t)args.n_seg; }
         if (run >= (uint32_t)args.n_runs) break;
+        const bool counting = SEG && args.mode == 1;
+        // ray range of this unit
+        const int64_t ray_lo = SEG ? (int64_t)seg * args.seg_len : 0;
+        const int64_t ray_hi = SEG ? ((ray_lo + args.seg_len < N) ? ray_lo + args.seg_len : N) : N;
 
         // ---- load the positioned heads and the stream head ----------------
         // gen/pos are kept modulo 2^32 (ring slots only need the low 10 bits,
@@ -1252,7 +1353,8 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
             for (int k = 0; k < 6; k++) {
                 hgen[k] = 0; hpos[k] = 0;
                 if ((S.array_used >> k) & 1u) {
-                    const KStream* src = args.heads + (size_t)run * nh + h;
+                    const KStream* src = SEG ? args.heads + (size_t)run * args.run_stride + (size_t)seg * nh + h
+                                             : args.heads + (size_t)run * nh + h;
                     uint32_t* r = rings + h * XRT_RING;
                     for (int i = tid; i < (int)XRT_RING; i += XRT_TILE) r[i] = src->ring[i];
                     hgen[k] = uni32((uint32_t)src->gen);
@@ -1262,11 +1364,24 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
             }
         }
         KStream* st = args.streams + run;
-        for (int i = tid; i < (int)XRT_RING; i += XRT_TILE) stream[i] = st->ring[i];
-        const uint64_t s_next0 = uni64(st->next), s_gen0 = uni64(st->gen);
+        // the stream head: the run's own, or (SEG) the chunk head at or before this unit's first
+        // Bragg uniform, which lies 2 * (candidates of the earlier segments) words into the draws
+        uint64_t seg_skip = 0;
+        const KStream* st_in = st;
+        if (SEG && args.mode == 2 && be >= 0) {
+            uint64_t before = 0;
+            for (uint32_t q = 0; q < seg; q++) before += args.unit_count[(size_t)run * args.n_seg + q];
+            const uint64_t words = 2ull * before;
+            const uint64_t chunk = words / (uint64_t)args.chunk_words;
+            seg_skip = words - chunk * (uint64_t)args.chunk_words;
+            st_in = args.chunk_heads + (size_t)run * args.run_stride + chunk;
+        }
+        for (int i = tid; i < (int)XRT_RING; i += XRT_TILE) stream[i] = st_in->ring[i];
+        const uint64_t s_next0 = uni64(st_in->next), s_gen0 = uni64(st_in->gen);
         uint32_t sgen = (uint32_t)s_gen0, spos = (uint32_t)s_next0;
         uint64_t s_used = 0;
         uint32_t qhead = 0, qcount = 0;
+        uint32_t n_candidates = 0;
         if (tid < XRT_DEV_MAX_OPTICS + 1) cnt[tid] = 0ULL;
         __syncthreads();
 
@@ -1313,6 +1428,15 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
                 if ((S.array_used >> k) & 1u) sh = sh || ((hgen[k] - hpos[k]) < XRT_AHEAD);
             return sh;
         };
+
+        if (SEG) {
+            // walk the stream head to this unit's first Bragg uniform (< chunk_words words)
+            while (seg_skip > 0) {
+                while ((sgen - spos) < XRT_AHEAD) { mt_step(); __syncthreads(); }
+                const uint32_t take = seg_skip < (uint64_t)XRT_AHEAD ? (uint32_t)seg_skip : XRT_AHEAD;
+                spos += take; s_used += take; seg_skip -= take;
+            }
+        }
 
         // Bragg angle shared by all rays when the wavelength is one constant
         const bool wl_shared = (S.wavelength_dist == XRT_WL_CONST) && !S.has_velocity;
@@ -1379,8 +1503,8 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
                 uint32_t n_out;
                 mt_step();
                 uint32_t rank = wg_rank(alive, wave_tot, slot, tid, n_out);
-                if (tid == 0) cnt[e + 1] += n_out;
-                const bool image = (op.flags & XRT_F_IMAGE) && args.images;
+                if (tid == 0 && !counting) cnt[e + 1] += n_out;
+                const bool image = (op.flags & XRT_F_IMAGE) && args.images && !counting;
                 if (e + 1 < sc.n_optics && n_out > 0) {
                     if (alive) q_store(q_wrap(scratch + rank), ray.o, ray.d, ray.wl, id);
                     mt_step();
@@ -1400,8 +1524,8 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
         };
 
         // ---- tiles of 256 rays in original order ----------------------------
-        for (int64_t i0 = 0; i0 < N; i0 += XRT_TILE) {
-            const int64_t left = N - i0;
+        for (int64_t i0 = ray_lo; i0 < ray_hi; i0 += XRT_TILE) {
+            const int64_t left = ray_hi - i0;
             const uint32_t n_tile = left < XRT_TILE ? (uint32_t)left : (uint32_t)XRT_TILE;
 
             // everything this tile consumes must be generated: normally already
@@ -1431,10 +1555,21 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
             int aux = 0;
             bool have = (uint32_t)tid < n_tile, alive = false;
             source_ray<FULL>(S, u, ray);
-            if (tid == 0) cnt[0] += n_tile;
+            if (tid == 0 && !counting) cnt[0] += n_tile;
             if (HIST && have) hist_write(args.hist, args.hmask, N, 0, id, ray.o, ray.d, ray.wl, true);
 
             // elements in config order (objects/_Dispatcher.py:166-196) up to the Bragg element
+            if (counting) {
+                // mode 1: only the number of rays that reach the Bragg test matters
+                const int stop = plain_elements(0, true, n_tile, have, alive, ray, X, id, aux, 0u);
+                if (stop >= 0) {
+                    uint32_t n_a;
+                    mt_step();
+                    wg_rank(alive, wave_tot, slot, tid, n_a);
+                    n_candidates += n_a;
+                }
+                continue;
+            }
             const int stop = plain_elements(0, true, n_tile, have, alive, ray, X, id, aux, q_wrap(qhead + qcount));
             if (stop >= 0) {
                 // queue the candidates in ray order: ordered live rank -> FIFO position
@@ -1450,7 +1585,7 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
             }
 
             // ---- Bragg test + the remaining elements, 128 queued rays at a time -----------
-            const bool last_tile = (i0 + XRT_TILE >= N);
+            const bool last_tile = (i0 + XRT_TILE >= ray_hi);
             while (be >= 0 && (qcount >= 128u || (last_tile && qcount > 0u))) {
                 const KOptic& op = sc.opt[be];
                 const uint32_t nb = qcount < 128u ? qcount : 128u;
@@ -1504,12 +1639,22 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
         // ---- run done: counters out, stream head back to memory ---------------
         // canonical form: exactly 512 words generated ahead (what xrt_jump_kernel expects)
         __syncthreads();
+        if (counting) {
+            if (tid == 0) args.unit_count[unit] = n_candidates;
+            __syncthreads();
+            continue;
+        }
         if (!HIST) while ((sgen - spos) < XRT_AHEAD) { mt_step(); __syncthreads(); }
         if (tid <= sc.n_optics && cnt[tid] != 0ULL) atomicAdd(&args.num_out[tid], cnt[tid]);
-        for (int i = tid; i < (int)XRT_RING; i += XRT_TILE) st->ring[i] = stream[i];
-        if (tid == 0) {
-            st->next = s_next0 + s_used;
-            st->gen = s_gen0 + (uint64_t)(uint32_t)(sgen - (uint32_t)s_gen0);
+        // the stream head goes back to memory: always for a whole run; of a segmented run only the
+        // last segment knows where the run's stream ends (without a Bragg optic nothing was drawn and
+        // the head positioned by the jump already is the result)
+        if (!SEG || (be >= 0 && seg + 1u == (uint32_t)args.n_seg)) {
+            for (int i = tid; i < (int)XRT_RING; i += XRT_TILE) st->ring[i] = stream[i];
+            if (tid == 0) {
+                st->next = s_next0 + s_used;
+                st->gen = s_gen0 + (uint64_t)(uint32_t)(sgen - (uint32_t)s_gen0);
+            }
         }
         __syncthreads();
     }
@@ -1713,11 +1858,47 @@ static size_t staged_bytes(const xrt_scene_t* sc, int n_runs)
     return al256((size_t)staged_slots(sc, n_runs) * staged_slot_bytes(sc) + 256);
 }
 
+// Few runs of many rays: split every run into segments so that the whole chip has work
+// (the unit of parallelism is otherwise one workgroup per run).  seg_len is a multiple of the tile.
+struct SegPlan { int n_seg; int64_t seg_len; };
+static SegPlan plan_segments(const xrt_scene_t* sc, int n_runs)
+{
+    SegPlan p = {1, 0};
+    if (needs_staged(sc)) return p;
+    const int64_t N = sc->source.intensity;
+    int want = 0;
+    int64_t min_len = 32768;                    // below this the jump-ahead of a unit's heads outweighs its rays
+    if (const char* e = getenv("XICSRT_SEGMENTS")) { want = atoi(e); min_len = XRT_TILE; }
+    else if (n_runs < 256) want = (1024 + n_runs - 1) / n_runs;
+    if (want <= 1 || N < 2 * XRT_TILE || getenv("XICSRT_NO_JUMP")) return p;
+    int64_t len = (N + want - 1) / want;
+    if (len < min_len) len = min_len;
+    len = (len + XRT_TILE - 1) / XRT_TILE * XRT_TILE;
+    const int64_t n = (N + len - 1) / len;
+    if (n <= 1 || n > 4096) return p;
+    p.n_seg = (int)n; p.seg_len = len;
+    return p;
+}
+// segmented runs: [dst heads n_runs x n_jobs][polys][offsets][unit counts]
+static int seg_jobs(const xrt_scene_t* sc, const SegPlan& p) { return p.n_seg * count_heads(sc) + p.n_seg + 1; }
+static size_t seg_bytes(const xrt_scene_t* sc, int n_runs)
+{
+    const SegPlan p = plan_segments(sc, n_runs);
+    if (p.n_seg <= 1) return 0;
+    const size_t nj = (size_t)seg_jobs(sc, p);
+    return al256(sizeof(KStream) * nj * (size_t)n_runs) + al256(sizeof(uint32_t) * 624 * nj) + al256(sizeof(uint64_t) * nj)
+           + al256(sizeof(uint32_t) * (size_t)n_runs * (size_t)p.n_seg) + 256;
+}
+
 extern "C" size_t xrt_workspace_bytes(const xrt_scene_t* sc, int32_t n_runs)
 {
     if (!sc || n_runs < 0) return 0;
     if (n_runs < 1) n_runs = 1;
-    return ws_off_staged(sc, n_runs) + staged_bytes(sc, n_runs) + meshes_bytes(sc) + plasma_bytes(sc) + 256;
+    return ws_off_staged(sc, n_runs) + staged_bytes(sc, n_runs) + meshes_bytes(sc) + plasma_bytes(sc) + seg_bytes(sc, n_runs) + 256;
+}
+static size_t ws_off_seg(const xrt_scene_t* sc, int n_runs)
+{
+    return al256(ws_off_staged(sc, n_runs) + staged_bytes(sc, n_runs) + meshes_bytes(sc) + plasma_bytes(sc));
 }
 
 // fused-kernel variant 2: an optic traced in its local frame, or a mesh
@@ -1967,10 +2148,10 @@ static int upload_tables(const xrt_scene_t* sc, char* ws, hipStream_t stream)
     return 0;
 }
 
-template <bool HIST, int VARIANT>
+template <bool HIST, int VARIANT, bool SEG = false>
 static int launch_variant(const KScene& ks, const KArgs& a, int n_runs, size_t lds, hipStream_t stream)
 {
-    auto kern = xrt_trace_kernel<HIST, VARIANT>;
+    auto kern = xrt_trace_kernel<HIST, VARIANT, SEG>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int dev = 0, cus = 256, per_cu = 1;
     HIP_TRY(hipGetDevice(&dev));
@@ -1980,7 +2161,8 @@ static int launch_variant(const KScene& ks, const KArgs& a, int n_runs, size_t l
     if (per_cu > 8) per_cu = 8;
     if (const char* cap = getenv("XICSRT_MAX_WG_PER_CU")) { int c = atoi(cap); if (c >= 1 && c < per_cu) per_cu = c; }
     int grid = cus * per_cu;
-    if (grid > n_runs) grid = n_runs;
+    const int units = SEG ? n_runs * a.n_seg : n_runs;
+    if (grid > units) grid = units;
     if (grid < 1) grid = 1;
     int ti = -1;
     if (timing_on && timing_n < TIMING_MAX) {
@@ -2044,6 +2226,72 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
         hipLaunchKernelGGL(kern, dim3(slots), dim3(XRT_TILE), lds, stream, ks, a, g);
         HIP_TRY(hipGetLastError());
         if (ti >= 0) HIP_TRY(hipEventRecord(timing_ev[ti][1], stream));
+        return 0;
+    }
+    const SegPlan plan = (canonical && !hist) ? plan_segments(sc, n_runs) : SegPlan{1, 0};
+    if (plan.n_seg > 1) {
+        // ---- segmented runs -------------------------------------------------------------------------
+        const int S = plan.n_seg, nj = seg_jobs(sc, plan);
+        const int64_t L = plan.seg_len, CH = 2 * L;
+        int be = -1;
+        for (int e = 0; e < sc->n_optics; e++)
+            if (sc->optics[e].interact == XRT_INTERACT_CRYSTAL && (sc->optics[e].flags & XRT_F_CHECK_BRAGG)) be = e;
+        char* base = ws + ws_off_seg(sc, n_runs);
+        KStream* dst = reinterpret_cast<KStream*>(base);
+        uint32_t* d_polys = reinterpret_cast<uint32_t*>(base + al256(sizeof(KStream) * (size_t)nj * (size_t)n_runs));
+        uint64_t* d_off = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(d_polys) + al256(sizeof(uint32_t) * 624 * (size_t)nj));
+        uint32_t* d_cnt = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(d_off) + al256(sizeof(uint64_t) * (size_t)nj));
+        // jobs of a run: [segment][source head], then the chunk heads, then the stream head behind the arrays
+        static thread_local std::vector<uint64_t> offs;
+        static thread_local std::vector<uint32_t> polys;
+        offs.assign((size_t)nj, 0);
+        int j = 0;
+        for (int sgm = 0; sgm < S; sgm++)
+            for (int k = 0; k < ks.src.n_arrays; k++)
+                if ((ks.src.array_used >> k) & 1u) offs[j++] = 2ull * ((uint64_t)k * (uint64_t)N + (uint64_t)sgm * (uint64_t)L);
+        const uint64_t behind = 2ull * (uint64_t)ks.src.n_arrays * (uint64_t)N;
+        for (int c = 0; c < S; c++) offs[j++] = behind + (uint64_t)c * (uint64_t)CH;
+        offs[j++] = behind;
+        if (j != nj) return fail(-5, "%s", "segment job count mismatch");
+        polys.assign((size_t)nj * 624, 0);
+        {
+            std::vector<uint64_t> Js;
+            std::vector<int> where;
+            for (int q = 0; q < nj; q++) if (offs[q] >= (uint64_t)XRT_AHEAD) { Js.push_back(offs[q] - (uint64_t)XRT_AHEAD); where.push_back(q); }
+            std::vector<uint32_t> tmp(Js.size() * 624);
+            if (!mtjump::jump_polys(Js.data(), (int)Js.size(), tmp.data()))
+                return fail(-5, "%s", "MT19937 characteristic polynomial could not be derived");
+            for (size_t q = 0; q < Js.size(); q++) memcpy(&polys[(size_t)where[q] * 624], &tmp[q * 624], 624 * sizeof(uint32_t));
+        }
+        HIP_TRY(hipMemcpyAsync(d_polys, polys.data(), sizeof(uint32_t) * 624 * (size_t)nj, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(d_off, offs.data(), sizeof(uint64_t) * (size_t)nj, hipMemcpyHostToDevice, stream));
+        KJumpJobs jobs;
+        jobs.polys = d_polys; jobs.offsets = d_off; jobs.dst = dst; jobs.n_jobs = nj; jobs.n_runs = n_runs;
+        const size_t jl = sizeof(uint32_t) * (size_t)XRT_STRETCH;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(xrt_jump_jobs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)jl));
+        int gy = (1024 + n_runs - 1) / n_runs;
+        if (gy > nj) gy = nj;
+        if (gy < 1) gy = 1;
+        hipLaunchKernelGGL(xrt_jump_jobs_kernel, dim3(n_runs, gy), dim3(XRT_JUMP_THREADS), jl, stream, streams, jobs);
+        HIP_TRY(hipGetLastError());
+        a.streams = streams; a.heads = dst; a.n_runs = n_runs; a.n_src_heads = nh;
+        a.run_counter = reinterpret_cast<uint32_t*>(ws);
+        a.n_seg = S; a.seg_len = L; a.unit_count = d_cnt; a.chunk_heads = dst + (size_t)S * nh; a.chunk_words = CH;
+        a.run_stride = nj;
+        const int variant = needs_ext(sc) ? 2 : (needs_full(sc) ? 1 : 0);
+        const size_t lds = lds_bytes(nh, variant == 2);
+        for (int mode = (be >= 0 ? 1 : 2); mode <= 2; mode++) {
+            a.mode = mode;
+            HIP_TRY(hipMemsetAsync(ws, 0, 64, stream));
+            int st = variant == 2 ? launch_variant<false, 2, true>(ks, a, n_runs, lds, stream)
+                   : variant == 1 ? launch_variant<false, 1, true>(ks, a, n_runs, lds, stream)
+                                  : launch_variant<false, 0, true>(ks, a, n_runs, lds, stream);
+            if (st) return st;
+        }
+        if (be < 0) {   // nothing was drawn behind the source arrays: the positioned head is the run's new stream head
+            hipLaunchKernelGGL(xrt_copy_streams_kernel, dim3(n_runs), dim3(256), 0, stream, streams, dst + (size_t)(nj - 1), (int64_t)nj, n_runs);
+            HIP_TRY(hipGetLastError());
+        }
         return 0;
     }
     static const bool no_jump = getenv("XICSRT_NO_JUMP") != nullptr;
