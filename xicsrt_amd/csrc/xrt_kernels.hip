@@ -1454,47 +1454,73 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
                 const KOptic& op = sc.opt[e];
                 if (fresh) {
                     alive = false;
-                    const bool local = EXT && (op.flags & XRT_F_TRACE_LOCAL);
-                    const bool is_mesh = EXT && (op.shape == XRT_SHAPE_MESH);
-                    if (have) {
-                        if (local) {    // TraceObject.trace_global -> ray_to_local (optics/_TraceObject.py:146-148)
-                            ray.o = to_local(op.R, sub3(ray.o, ld3(op.origin)));
-                            ray.d = to_local(op.R, ray.d);
-                        }
-                        bool hit;
-                        if (is_mesh) {
-                            const MeshHit h = mesh_hit(op.mesh, ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z);
-                            hit = h.hit != 0; X.x = h.x; X.y = h.y; X.z = h.z; aux = h.aux;
-                        } else hit = intersect_point<FULL>(op, ray, X);
-                        alive = hit && check_bounds<FULL>(op, X);
-                        if (HIST && !alive) {
-                            V3 xo = X, dd = ray.d;
-                            if (!hit) { xo.x = xo.y = xo.z = __builtin_nan(""); }
-                            if (local) {
-                                xo = to_external(op.R, xo);
-                                xo.x += op.origin[0]; xo.y += op.origin[1]; xo.z += op.origin[2];
-                                dd = to_external(op.R, dd);
+                    // (the EXT parts are discarded statements in the other variants: even dead code here
+                    //  perturbs the register allocation of the lean kernel measurably)
+                    if constexpr (EXT) {
+                        const bool local = (op.flags & XRT_F_TRACE_LOCAL) != 0;
+                        const bool is_mesh = (op.shape == XRT_SHAPE_MESH);
+                        if (have) {
+                            if (local) {    // TraceObject.trace_global -> ray_to_local (optics/_TraceObject.py:146-148)
+                                ray.o = to_local(op.R, sub3(ray.o, ld3(op.origin)));
+                                ray.d = to_local(op.R, ray.d);
                             }
-                            hist_write(args.hist, args.hmask, N, e + 1, id, xo, dd, ray.wl, false);
+                            bool hit;
+                            if (is_mesh) {
+                                const MeshHit h = mesh_hit(op.mesh, ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z);
+                                hit = h.hit != 0; X.x = h.x; X.y = h.y; X.z = h.z; aux = h.aux;
+                            } else hit = intersect_point<FULL>(op, ray, X);
+                            alive = hit && check_bounds<FULL>(op, X);
+                            if (HIST && !alive) {
+                                V3 xo = X, dd = ray.d;
+                                if (!hit) { xo.x = xo.y = xo.z = __builtin_nan(""); }
+                                if (local) {
+                                    xo = to_external(op.R, xo);
+                                    xo.x += op.origin[0]; xo.y += op.origin[1]; xo.z += op.origin[2];
+                                    dd = to_external(op.R, dd);
+                                }
+                                hist_write(args.hist, args.hmask, N, e + 1, id, xo, dd, ray.wl, false);
+                            }
                         }
-                    }
-                    if (e == be) return e;                       // candidates for the Bragg queue
-                    // InteractObject / InteractMirror.reflect_vectors (optics/_InteractMirror.py:29-42)
-                    if (alive) {
-                        ray.o = X;
-                        if (op.interact != XRT_INTERACT_NONE) {
-                            V3 nrm = is_mesh ? mesh_normal(op.mesh, X.x, X.y, aux) : surface_normal<FULL>(op, X);
-                            double dt = dot_e(ray.d, nrm);
-                            ray.d.x = ray.d.x - 2.0 * (dt * nrm.x);
-                            ray.d.y = ray.d.y - 2.0 * (dt * nrm.y);
-                            ray.d.z = ray.d.z - 2.0 * (dt * nrm.z);
+                        if (e == be) return e;                   // candidates for the Bragg queue
+                        if (alive) {
+                            ray.o = X;
+                            if (op.interact != XRT_INTERACT_NONE) {
+                                V3 nrm = is_mesh ? mesh_normal(op.mesh, X.x, X.y, aux) : surface_normal<FULL>(op, X);
+                                double dt = dot_e(ray.d, nrm);
+                                ray.d.x = ray.d.x - 2.0 * (dt * nrm.x);
+                                ray.d.y = ray.d.y - 2.0 * (dt * nrm.y);
+                                ray.d.z = ray.d.z - 2.0 * (dt * nrm.z);
+                            }
+                            if (local) {    // ray_to_external (optics/_TraceObject.py:152-154)
+                                ray.o = to_external(op.R, ray.o);
+                                ray.o.x += op.origin[0]; ray.o.y += op.origin[1]; ray.o.z += op.origin[2];
+                                ray.d = to_external(op.R, ray.d);
+                            }
+                            if (HIST) hist_write(args.hist, args.hmask, N, e + 1, id, ray.o, ray.d, ray.wl, true);
                         }
-                        if (local) {    // ray_to_external (optics/_TraceObject.py:152-154)
-                            ray.o = to_external(op.R, ray.o);
-                            ray.o.x += op.origin[0]; ray.o.y += op.origin[1]; ray.o.z += op.origin[2];
-                            ray.d = to_external(op.R, ray.d);
+                    } else {
+                        if (have) {
+                            bool hit = intersect_point<FULL>(op, ray, X);
+                            alive = hit && check_bounds<FULL>(op, X);
+                            if (HIST && !alive) {
+                                V3 xo = X;
+                                if (!hit) { xo.x = xo.y = xo.z = __builtin_nan(""); }
+                                hist_write(args.hist, args.hmask, N, e + 1, id, xo, ray.d, ray.wl, false);
+                            }
                         }
-                        if (HIST) hist_write(args.hist, args.hmask, N, e + 1, id, ray.o, ray.d, ray.wl, true);
+                        if (e == be) return e;                   // candidates for the Bragg queue
+                        // InteractObject / InteractMirror.reflect_vectors (optics/_InteractMirror.py:29-42)
+                        if (alive) {
+                            ray.o = X;
+                            if (op.interact != XRT_INTERACT_NONE) {
+                                V3 nrm = surface_normal<FULL>(op, X);
+                                double dt = dot_e(ray.d, nrm);
+                                ray.d.x = ray.d.x - 2.0 * (dt * nrm.x);
+                                ray.d.y = ray.d.y - 2.0 * (dt * nrm.y);
+                                ray.d.z = ray.d.z - 2.0 * (dt * nrm.z);
+                            }
+                            if (HIST) hist_write(args.hist, args.hmask, N, e + 1, id, ray.o, ray.d, ray.wl, true);
+                        }
                     }
                 }
                 fresh = true;
@@ -1577,9 +1603,13 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
                 uint32_t n_a;
                 mt_step();
                 uint32_t rank = wg_rank(alive, wave_tot, slot, tid, n_a);
-                if (alive) {
-                    q_store(q_wrap(qhead + qcount + rank), X, ray.d, ray.wl, id);
-                    if (EXT) qaux[q_wrap(qhead + qcount + rank)] = (uint32_t)aux;
+                if constexpr (EXT) {
+                    if (alive) {
+                        q_store(q_wrap(qhead + qcount + rank), X, ray.d, ray.wl, id);
+                        qaux[q_wrap(qhead + qcount + rank)] = (uint32_t)aux;
+                    }
+                } else {
+                    if (alive) q_store(q_wrap(qhead + qcount + rank), X, ray.d, ray.wl, id);
                 }
                 qcount += n_a;
             }
@@ -1595,36 +1625,55 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
                 __syncthreads();                                  // queue records visible
                 have = (uint32_t)tid < nb;
                 alive = false;
-                const bool local = EXT && (op.flags & XRT_F_TRACE_LOCAL);
-                if (have) {
-                    q_load(q_wrap(qhead + (uint32_t)tid), X, ray.d, ray.wl, id);
-                    V3 nrm;
-                    if (EXT && op.shape == XRT_SHAPE_MESH) nrm = mesh_normal(op.mesh, X.x, X.y, (int)qaux[q_wrap(qhead + (uint32_t)tid)]);
-                    else nrm = surface_normal<FULL>(op, X);
-                    uint32_t n = spos + 2u * (uint32_t)tid;
-                    double test = 0.0 + (1.0 - 0.0) * mt_double(stream[n & XRT_RMASK], stream[(n + 1u) & XRT_RMASK]);
-                    alive = bragg_accept(op, ray, nrm, test, wl_shared, bragg_shared);
-                    if (HIST && !alive) {
-                        V3 xo = X, dd = ray.d;
-                        if (local) {
-                            xo = to_external(op.R, xo);
-                            xo.x += op.origin[0]; xo.y += op.origin[1]; xo.z += op.origin[2];
-                            dd = to_external(op.R, dd);
+                if constexpr (EXT) {
+                    const bool local = (op.flags & XRT_F_TRACE_LOCAL) != 0;
+                    if (have) {
+                        q_load(q_wrap(qhead + (uint32_t)tid), X, ray.d, ray.wl, id);
+                        V3 nrm;
+                        if (op.shape == XRT_SHAPE_MESH) nrm = mesh_normal(op.mesh, X.x, X.y, (int)qaux[q_wrap(qhead + (uint32_t)tid)]);
+                        else nrm = surface_normal<FULL>(op, X);
+                        uint32_t n = spos + 2u * (uint32_t)tid;
+                        double test = 0.0 + (1.0 - 0.0) * mt_double(stream[n & XRT_RMASK], stream[(n + 1u) & XRT_RMASK]);
+                        alive = bragg_accept(op, ray, nrm, test, wl_shared, bragg_shared);
+                        if (HIST && !alive) {
+                            V3 xo = X, dd = ray.d;
+                            if (local) {
+                                xo = to_external(op.R, xo);
+                                xo.x += op.origin[0]; xo.y += op.origin[1]; xo.z += op.origin[2];
+                                dd = to_external(op.R, dd);
+                            }
+                            hist_write(args.hist, args.hmask, N, be + 1, id, xo, dd, ray.wl, false);
                         }
-                        hist_write(args.hist, args.hmask, N, be + 1, id, xo, dd, ray.wl, false);
+                        if (alive) {
+                            ray.o = X;
+                            double dt = dot_e(ray.d, nrm);
+                            ray.d.x = ray.d.x - 2.0 * (dt * nrm.x);
+                            ray.d.y = ray.d.y - 2.0 * (dt * nrm.y);
+                            ray.d.z = ray.d.z - 2.0 * (dt * nrm.z);
+                            if (local) {
+                                ray.o = to_external(op.R, ray.o);
+                                ray.o.x += op.origin[0]; ray.o.y += op.origin[1]; ray.o.z += op.origin[2];
+                                ray.d = to_external(op.R, ray.d);
+                            }
+                            if (HIST) hist_write(args.hist, args.hmask, N, be + 1, id, ray.o, ray.d, ray.wl, true);
+                        }
                     }
-                    if (alive) {
-                        ray.o = X;
-                        double dt = dot_e(ray.d, nrm);
-                        ray.d.x = ray.d.x - 2.0 * (dt * nrm.x);
-                        ray.d.y = ray.d.y - 2.0 * (dt * nrm.y);
-                        ray.d.z = ray.d.z - 2.0 * (dt * nrm.z);
-                        if (local) {
-                            ray.o = to_external(op.R, ray.o);
-                            ray.o.x += op.origin[0]; ray.o.y += op.origin[1]; ray.o.z += op.origin[2];
-                            ray.d = to_external(op.R, ray.d);
+                } else {
+                    if (have) {
+                        q_load(q_wrap(qhead + (uint32_t)tid), X, ray.d, ray.wl, id);
+                        V3 nrm = surface_normal<FULL>(op, X);
+                        uint32_t n = spos + 2u * (uint32_t)tid;
+                        double test = 0.0 + (1.0 - 0.0) * mt_double(stream[n & XRT_RMASK], stream[(n + 1u) & XRT_RMASK]);
+                        alive = bragg_accept(op, ray, nrm, test, wl_shared, bragg_shared);
+                        if (HIST && !alive) hist_write(args.hist, args.hmask, N, be + 1, id, X, ray.d, ray.wl, false);
+                        if (alive) {
+                            ray.o = X;
+                            double dt = dot_e(ray.d, nrm);
+                            ray.d.x = ray.d.x - 2.0 * (dt * nrm.x);
+                            ray.d.y = ray.d.y - 2.0 * (dt * nrm.y);
+                            ray.d.z = ray.d.z - 2.0 * (dt * nrm.z);
+                            if (HIST) hist_write(args.hist, args.hmask, N, be + 1, id, ray.o, ray.d, ray.wl, true);
                         }
-                        if (HIST) hist_write(args.hist, args.hmask, N, be + 1, id, ray.o, ray.d, ray.wl, true);
                     }
                 }
                 spos += 2u * nb;
