@@ -1069,15 +1069,62 @@ void xrt_seek_kernel(KStream* streams, KStream* heads, int n_runs, int n_arrays,
 // first word (J_k = 2kN - 512 from the canonical stream form gen = next + 512).
 // Cost is independent of N; the sequential xrt_seek_kernel remains the general path.
 #define XRT_JUMP_THREADS 1024
+// One jump: O[w] = XOR over the set bits j of g (624 mask words) of S[w + j], w < 624.
+// Thread (block b < 156, part p < 5; a part is three whole waves, so the mask word is wave-uniform)
+// accumulates the four outputs 4b..4b+3 over the mask words [125 p, 125 p + 125): per four bits it needs one aligned 128-bit LDS read (the window of
+// S[4b + j .. 4b + j + 6] slides by a quad) and sixteen masked XORs -- no scalar bit scanning, no
+// data-dependent branches; the five partial results meet in O through LDS atomics.
+// S must be readable up to index XRT_STRETCH + 36 (only ever multiplied by zero mask bits there).  O must be zero on entry; ends with a barrier.
+#define XRT_JUMP_PARTS 5
+// acc ^ (x & mask) in one gfx950 instruction (v_bitop3_b32, truth table 0x6A with a = 0xF0, b = 0xCC, c = 0xAA)
+__device__ __forceinline__ uint32_t mxor(uint32_t acc, uint32_t x, uint32_t mask) {
+#ifndef XRT_JUMP_NO_BITOP3
+    return __builtin_amdgcn_bitop3_b32(x, mask, acc, 0x6A);
+#else
+    return acc ^ (x & mask);
+#endif
+}
+
+__device__ __forceinline__ void jump_xor(const uint32_t* S, const uint32_t* g, uint32_t* O, int tid)
+{
+    const int p = tid / 192, b = tid - p * 192;
+    if (p < XRT_JUMP_PARTS && b < 156) {
+        const uint4* Sq = reinterpret_cast<const uint4*>(S + 4 * b);    // quad n = S[4b + 4n .. 4b + 4n + 3]
+        uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        const int w0 = 125 * p, w1 = (w0 + 125 < 624) ? w0 + 125 : 624;
+        uint4 cur = Sq[8 * w0], nxt = Sq[8 * w0 + 1];
+        for (int mw = w0; mw < w1; mw++) {
+            const uint32_t m = uni32(g[mw]);
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const uint4 far = Sq[8 * mw + t + 2];
+                const uint32_t x0 = cur.x, x1 = cur.y, x2 = cur.z, x3 = cur.w, x4 = nxt.x, x5 = nxt.y, x6 = nxt.z;
+                const uint32_t k0 = 0u - ((m >> (4 * t + 0)) & 1u), k1 = 0u - ((m >> (4 * t + 1)) & 1u);
+                const uint32_t k2 = 0u - ((m >> (4 * t + 2)) & 1u), k3 = 0u - ((m >> (4 * t + 3)) & 1u);
+                a0 = mxor(a0, x0, k0); a1 = mxor(a1, x1, k0); a2 = mxor(a2, x2, k0); a3 = mxor(a3, x3, k0);
+                a0 = mxor(a0, x1, k1); a1 = mxor(a1, x2, k1); a2 = mxor(a2, x3, k1); a3 = mxor(a3, x4, k1);
+                a0 = mxor(a0, x2, k2); a1 = mxor(a1, x3, k2); a2 = mxor(a2, x4, k2); a3 = mxor(a3, x5, k2);
+                a0 = mxor(a0, x3, k3); a1 = mxor(a1, x4, k3); a2 = mxor(a2, x5, k3); a3 = mxor(a3, x6, k3);
+                cur = nxt; nxt = far;
+            }
+        }
+        atomicXor(&O[4 * b + 0], a0); atomicXor(&O[4 * b + 1], a1);
+        atomicXor(&O[4 * b + 2], a2); atomicXor(&O[4 * b + 3], a3);
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(XRT_JUMP_THREADS)
 void xrt_jump_kernel(KStream* streams, KStream* heads, const uint32_t* polys, int n_runs, int n_arrays,
                      uint32_t array_used, int n_src_heads, int n_polys, int64_t n_rays)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t jlds[];
-    uint32_t* S = jlds;                         // [XRT_STRETCH]
-    uint32_t* P = jlds + XRT_STRETCH;           // [n_polys][624]
+    uint32_t* S = jlds;                         // [XRT_STRETCH + 48]
+    uint32_t* O = jlds + XRT_STRETCH + 48;      // [624] one jump's result
+    uint32_t* P = O + 624;                      // [n_polys][624]
     const int tid = threadIdx.x;
     for (int i = tid; i < n_polys * 624; i += XRT_JUMP_THREADS) P[i] = polys[i];
+    if (tid < 48) S[XRT_STRETCH + tid] = 0u;
     for (int run = blockIdx.x; run < n_runs; run += gridDim.x) {
         KStream* st = streams + run;
         const uint64_t gen = uni64(st->gen), next = uni64(st->next);
@@ -1106,30 +1153,12 @@ void xrt_jump_kernel(KStream* streams, KStream* heads, const uint32_t* polys, in
             } else {
                 const uint32_t* g = P + pi * 624;
                 pi++;
-                if (tid < 624) {        // one output word per thread (waves 0..9)
-                    uint32_t acc = 0;
-                    const uint32_t* sx = S + tid;
-                    for (int b = 0; b < 624; b++) {
-                        uint32_t m = uni32(g[b]);
-                        const uint32_t* base = sx + 32 * b;
-                        // four loads in flight per trip while the mask has that many bits left
-                        while (__builtin_popcount(m) >= 4) {
-                            const int i0 = __builtin_ctz(m); m &= m - 1u;
-                            const int i1 = __builtin_ctz(m); m &= m - 1u;
-                            const int i2 = __builtin_ctz(m); m &= m - 1u;
-                            const int i3 = __builtin_ctz(m); m &= m - 1u;
-                            const uint32_t a0 = base[i0], a1 = base[i1], a2 = base[i2], a3 = base[i3];
-                            acc ^= (a0 ^ a1) ^ (a2 ^ a3);
-                        }
-                        while (m) {
-                            const int i = __builtin_ctz(m);
-                            m &= m - 1u;
-                            acc ^= base[i];
-                        }
-                    }
-                    // window [target-624, target): only these 624 slots of the ring are meaningful
-                    out->ring[((uint32_t)target - 624u + (uint32_t)tid) & XRT_RMASK] = acc;
-                }
+                __syncthreads();
+                if (tid < 624) O[tid] = 0u;
+                __syncthreads();
+                jump_xor(S, g, O, tid);
+                // window [target-624, target): only these 624 slots of the ring are meaningful
+                if (tid < 624) out->ring[((uint32_t)target - 624u + (uint32_t)tid) & XRT_RMASK] = O[tid];
                 if (tid == 0) { out->gen = target; out->next = target; }
             }
             if (!is_stream) h++;
@@ -1182,8 +1211,10 @@ __global__ __launch_bounds__(XRT_JUMP_THREADS)
 void xrt_jump_jobs_kernel(const KStream* streams, const KJumpJobs jobs)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t jlds[];
-    uint32_t* S = jlds;                         // [XRT_STRETCH]
+    uint32_t* S = jlds;                         // [XRT_STRETCH + 48]
+    uint32_t* O = jlds + XRT_STRETCH + 48;      // [624]
     const int tid = threadIdx.x;
+    if (tid < 48) S[XRT_STRETCH + tid] = 0u;
     for (int run = blockIdx.x; run < jobs.n_runs; run += gridDim.x) {
         const KStream* st = streams + run;
         const uint64_t gen = uni64(st->gen), next = uni64(st->next);
@@ -1209,28 +1240,11 @@ void xrt_jump_jobs_kernel(const KStream* streams, const KJumpJobs jobs)
                 continue;
             }
             const uint32_t* g = jobs.polys + (size_t)j * 624;
-            if (tid < 624) {
-                uint32_t acc = 0;
-                const uint32_t* sx = S + tid;
-                for (int b = 0; b < 624; b++) {
-                    uint32_t m = uni32(g[b]);
-                    const uint32_t* base = sx + 32 * b;
-                    while (__builtin_popcount(m) >= 4) {
-                        const int i0 = __builtin_ctz(m); m &= m - 1u;
-                        const int i1 = __builtin_ctz(m); m &= m - 1u;
-                        const int i2 = __builtin_ctz(m); m &= m - 1u;
-                        const int i3 = __builtin_ctz(m); m &= m - 1u;
-                        const uint32_t a0 = base[i0], a1 = base[i1], a2 = base[i2], a3 = base[i3];
-                        acc ^= (a0 ^ a1) ^ (a2 ^ a3);
-                    }
-                    while (m) {
-                        const int i = __builtin_ctz(m);
-                        m &= m - 1u;
-                        acc ^= base[i];
-                    }
-                }
-                out->ring[((uint32_t)target - 624u + (uint32_t)tid) & XRT_RMASK] = acc;
-            }
+            __syncthreads();
+            if (tid < 624) O[tid] = 0u;
+            __syncthreads();
+            jump_xor(S, g, O, tid);
+            if (tid < 624) out->ring[((uint32_t)target - 624u + (uint32_t)tid) & XRT_RMASK] = O[tid];
             if (tid == 0) { out->gen = target; out->next = target; }
         }
     }
@@ -2316,7 +2330,7 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
         HIP_TRY(hipMemcpyAsync(d_off, offs.data(), sizeof(uint64_t) * (size_t)nj, hipMemcpyHostToDevice, stream));
         KJumpJobs jobs;
         jobs.polys = d_polys; jobs.offsets = d_off; jobs.dst = dst; jobs.n_jobs = nj; jobs.n_runs = n_runs;
-        const size_t jl = sizeof(uint32_t) * (size_t)XRT_STRETCH;
+        const size_t jl = sizeof(uint32_t) * ((size_t)XRT_STRETCH + 48 + 624);
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(xrt_jump_jobs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)jl));
         int gy = (1024 + n_runs - 1) / n_runs;
         if (gy > nj) gy = nj;
@@ -2358,7 +2372,7 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
         }
         uint32_t* d_polys = reinterpret_cast<uint32_t*>(ws + ws_off_polys(sc, n_runs));
         HIP_TRY(hipMemcpyAsync(d_polys, hpolys.data(), sizeof(uint32_t) * 624 * (size_t)n_polys, hipMemcpyHostToDevice, stream));
-        const size_t jl = sizeof(uint32_t) * ((size_t)XRT_STRETCH + 624 * (size_t)n_polys);
+        const size_t jl = sizeof(uint32_t) * ((size_t)XRT_STRETCH + 48 + 624 + 624 * (size_t)n_polys);
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(xrt_jump_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)jl));
         int dev = 0, cus = 256;
         HIP_TRY(hipGetDevice(&dev));
