@@ -204,3 +204,19 @@ def test_few_long_runs_are_segmented_and_equal_the_oracle():
     assert [int(meta[nm]['num_out']) for nm in flat.names] == [int(v) for v in o_num]
     got = np.concatenate([image[nm].ravel() for nm in flat.names[1:]]).astype(np.int64)
     assert np.array_equal(got, o_img[:flat.image_bins])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('bragg', [False, True])
+def test_segmented_runs_chain_iterations(bragg, monkeypatch):
+    """Segmented runs over several iterations (the stream head a segmented iteration leaves must be the
+    one the next iteration's jump expects), with and without Bragg draws: equal to the oracle."""
+    monkeypatch.setenv('XICSRT_SEGMENTS', '4')
+    cfg = _spectrometer(20000, 2, seed=77, check_bragg=bragg, rocking_fwhm=3e-3)
+    cfg['general']['number_of_iter'] = 3
+    config, elements, flat = helpers.build(cfg)
+    seeds = xrt.run_seeds(77, 2)
+    n_gpu, i_gpu = _trace(flat, seeds, 3)
+    n_cpu, i_cpu = helpers.oracle_counts(flat, seeds, 3)
+    assert np.array_equal(n_gpu, n_cpu), (n_gpu, n_cpu)
+    assert np.array_equal(i_gpu[:flat.image_bins], i_cpu[:flat.image_bins])

@@ -1250,16 +1250,6 @@ void xrt_jump_jobs_kernel(const KStream* streams, const KJumpJobs jobs)
     }
 }
 
-__global__ void xrt_copy_streams_kernel(KStream* dst, const KStream* src, int64_t src_stride, int n)
-{
-    // dst[r] = src[r * src_stride] (all 4128 bytes), one workgroup per stream
-    const int r = blockIdx.x;
-    if (r >= n) return;
-    const uint64_t* a = reinterpret_cast<const uint64_t*>(src + (size_t)r * src_stride);
-    uint64_t* b = reinterpret_cast<uint64_t*>(dst + r);
-    for (int i = threadIdx.x; i < (int)(sizeof(KStream) / 8); i += blockDim.x) b[i] = a[i];
-}
-
 // --------------------------------------------------------------------------
 // the propagation kernel
 // --------------------------------------------------------------------------
@@ -1383,12 +1373,23 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
         uint64_t seg_skip = 0;
         const KStream* st_in = st;
         if (SEG && args.mode == 2 && be >= 0) {
-            uint64_t before = 0;
-            for (uint32_t q = 0; q < seg; q++) before += args.unit_count[(size_t)run * args.n_seg + q];
+            // candidates of the earlier segments of this run, summed by the whole workgroup
+            if (tid == 0) cnt[0] = 0ULL;
+            __syncthreads();
+            unsigned long long part = 0;
+            for (uint32_t q = (uint32_t)tid; q < seg; q += XRT_TILE) part += args.unit_count[(size_t)run * args.n_seg + q];
+            if (part) atomicAdd(&cnt[0], part);
+            __syncthreads();
+            const uint64_t before = uni64(cnt[0]);
+            __syncthreads();
             const uint64_t words = 2ull * before;
             const uint64_t chunk = words / (uint64_t)args.chunk_words;
             seg_skip = words - chunk * (uint64_t)args.chunk_words;
             st_in = args.chunk_heads + (size_t)run * args.run_stride + chunk;
+        } else if (SEG && args.mode == 2 && be < 0 && seg + 1u == (uint32_t)args.n_seg) {
+            // no Bragg draws: the run's stream ends right behind the source arrays; the last segment brings
+            // that head (positioned by the jump, behind the chunk heads) into the canonical form and stores it
+            st_in = args.chunk_heads + (size_t)run * args.run_stride + args.n_seg;
         }
         for (int i = tid; i < (int)XRT_RING; i += XRT_TILE) stream[i] = st_in->ring[i];
         const uint64_t s_next0 = uni64(st_in->next), s_gen0 = uni64(st_in->gen);
@@ -1710,9 +1711,8 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
         if (!HIST) while ((sgen - spos) < XRT_AHEAD) { mt_step(); __syncthreads(); }
         if (tid <= sc.n_optics && cnt[tid] != 0ULL) atomicAdd(&args.num_out[tid], cnt[tid]);
         // the stream head goes back to memory: always for a whole run; of a segmented run only the
-        // last segment knows where the run's stream ends (without a Bragg optic nothing was drawn and
-        // the head positioned by the jump already is the result)
-        if (!SEG || (be >= 0 && seg + 1u == (uint32_t)args.n_seg)) {
+        // last segment knows where the run's stream ends
+        if (!SEG || seg + 1u == (uint32_t)args.n_seg) {
             for (int i = tid; i < (int)XRT_RING; i += XRT_TILE) st->ring[i] = stream[i];
             if (tid == 0) {
                 st->next = s_next0 + s_used;
@@ -1930,9 +1930,9 @@ static SegPlan plan_segments(const xrt_scene_t* sc, int n_runs)
     if (needs_staged(sc)) return p;
     const int64_t N = sc->source.intensity;
     int want = 0;
-    int64_t min_len = 32768;                    // below this the jump-ahead of a unit's heads outweighs its rays
+    int64_t min_len = 4096;                     // below this the jump-ahead of a unit's heads outweighs its rays
     if (const char* e = getenv("XICSRT_SEGMENTS")) { want = atoi(e); min_len = XRT_TILE; }
-    else if (n_runs < 256) want = (1024 + n_runs - 1) / n_runs;
+    else if (n_runs < 256) want = (512 + n_runs - 1) / n_runs;      // about two units per CU
     if (want <= 1 || N < 2 * XRT_TILE || getenv("XICSRT_NO_JUMP")) return p;
     int64_t len = (N + want - 1) / want;
     if (len < min_len) len = min_len;
@@ -2350,10 +2350,6 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
                    : variant == 1 ? launch_variant<false, 1, true>(ks, a, n_runs, lds, stream)
                                   : launch_variant<false, 0, true>(ks, a, n_runs, lds, stream);
             if (st) return st;
-        }
-        if (be < 0) {   // nothing was drawn behind the source arrays: the positioned head is the run's new stream head
-            hipLaunchKernelGGL(xrt_copy_streams_kernel, dim3(n_runs), dim3(256), 0, stream, streams, dst + (size_t)(nj - 1), (int64_t)nj, n_runs);
-            HIP_TRY(hipGetLastError());
         }
         return 0;
     }
