@@ -1069,6 +1069,28 @@ void xrt_seek_kernel(KStream* streams, KStream* heads, int n_runs, int n_arrays,
 // first word (J_k = 2kN - 512 from the canonical stream form gen = next + 512).
 // Cost is independent of N; the sequential xrt_seek_kernel remains the general path.
 #define XRT_JUMP_THREADS 1024
+// The 19937+623-word stretch behind a stream head's last 624 state words, built by ONE wave
+// (LDS operations of a wave execute in order, so no workgroup barrier is needed between the
+// dependent steps: <= 227 words are independent, 192 = 3 per lane are produced per step).
+__device__ __forceinline__ void build_stretch(uint32_t* S, int tid)
+{
+    if (tid < 64) {
+        for (int base = 624; base < XRT_STRETCH; base += 192) {
+            const int n0 = base + tid, n1 = n0 + 64, n2 = n0 + 128;
+            const bool v0 = n0 < XRT_STRETCH, v1 = n1 < XRT_STRETCH, v2 = n2 < XRT_STRETCH;
+            uint32_t r0 = 0, r1 = 0, r2 = 0;
+            if (v0) r0 = mt_mix(S[n0 - 624], S[n0 - 623], S[n0 - 227]);
+            if (v1) r1 = mt_mix(S[n1 - 624], S[n1 - 623], S[n1 - 227]);
+            if (v2) r2 = mt_mix(S[n2 - 624], S[n2 - 623], S[n2 - 227]);
+            if (v0) S[n0] = r0;
+            if (v1) S[n1] = r1;
+            if (v2) S[n2] = r2;
+            wave_fence();
+        }
+    }
+    __syncthreads();
+}
+
 // One jump: O[w] = XOR over the set bits j of g (624 mask words) of S[w + j], w < 624.
 // Thread (block b < 156, part p < 5; a part is three whole waves, so the mask word is wave-uniform)
 // accumulates the four outputs 4b..4b+3 over the mask words [125 p, 125 p + 125): per four bits it needs one aligned 128-bit LDS read (the window of
@@ -1131,15 +1153,7 @@ void xrt_jump_kernel(KStream* streams, KStream* heads, const uint32_t* polys, in
         __syncthreads();
         if (tid < 624) S[tid] = st->ring[((uint32_t)gen - 624u + (uint32_t)tid) & XRT_RMASK];
         __syncthreads();
-        for (int base = 624; base < XRT_STRETCH; base += 227) {
-            int chunk = XRT_STRETCH - base;
-            if (chunk > 227) chunk = 227;
-            if (tid < chunk) {
-                const int n = base + tid;
-                S[n] = mt_mix(S[n - 624], S[n - 623], S[n - 227]);
-            }
-            __syncthreads();
-        }
+        build_stretch(S, tid);
         int h = 0, pi = 0;
         for (int k = 0; k <= n_arrays; k++) {
             const bool is_stream = (k == n_arrays);
@@ -1221,15 +1235,7 @@ void xrt_jump_jobs_kernel(const KStream* streams, const KJumpJobs jobs)
         __syncthreads();
         if (tid < 624) S[tid] = st->ring[((uint32_t)gen - 624u + (uint32_t)tid) & XRT_RMASK];
         __syncthreads();
-        for (int base = 624; base < XRT_STRETCH; base += 227) {
-            int chunk = XRT_STRETCH - base;
-            if (chunk > 227) chunk = 227;
-            if (tid < chunk) {
-                const int n = base + tid;
-                S[n] = mt_mix(S[n - 624], S[n - 623], S[n - 227]);
-            }
-            __syncthreads();
-        }
+        build_stretch(S, tid);
         for (int j = blockIdx.y; j < jobs.n_jobs; j += gridDim.y) {
             KStream* out = jobs.dst + (size_t)run * jobs.n_jobs + j;
             const uint64_t off = jobs.offsets[j];
@@ -2215,13 +2221,20 @@ template <bool HIST, int VARIANT, bool SEG = false>
 static int launch_variant(const KScene& ks, const KArgs& a, int n_runs, size_t lds, hipStream_t stream)
 {
     auto kern = xrt_trace_kernel<HIST, VARIANT, SEG>;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int dev = 0, cus = 256, per_cu = 1;
+    // attribute and occupancy queries cost ~0.1 ms each: once per (device, LDS size) and instantiation
+    static thread_local int c_dev = -1, c_cus = 256, c_per_cu = 1;
+    static thread_local size_t c_lds = 0;
+    int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
-    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, XRT_TILE, lds));
-    if (per_cu < 1) per_cu = 1;
-    if (per_cu > 8) per_cu = 8;
+    if (dev != c_dev || lds != c_lds) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipDeviceGetAttribute(&c_cus, hipDeviceAttributeMultiprocessorCount, dev));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c_per_cu, kern, XRT_TILE, lds));
+        if (c_per_cu < 1) c_per_cu = 1;
+        if (c_per_cu > 8) c_per_cu = 8;
+        c_dev = dev; c_lds = lds;
+    }
+    int cus = c_cus, per_cu = c_per_cu;
     if (const char* cap = getenv("XICSRT_MAX_WG_PER_CU")) { int c = atoi(cap); if (c >= 1 && c < per_cu) per_cu = c; }
     int grid = cus * per_cu;
     const int units = SEG ? n_runs * a.n_seg : n_runs;
@@ -2305,6 +2318,21 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
         uint64_t* d_off = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(d_polys) + al256(sizeof(uint32_t) * 624 * (size_t)nj));
         uint32_t* d_cnt = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(d_off) + al256(sizeof(uint64_t) * (size_t)nj));
         // jobs of a run: [segment][source head], then the chunk heads, then the stream head behind the arrays
+        // polynomials + offsets of a plan live in pinned host memory and are reused by later calls
+        struct PlanCache { int64_t N, L; int S, nj; uint32_t used; int n_arrays; uint32_t* polys; uint64_t* offs; };
+        static std::mutex plan_mu;
+        static std::vector<PlanCache> plans;
+        PlanCache hit;
+        hit.polys = nullptr; hit.offs = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(plan_mu);
+            for (const PlanCache& c : plans)
+                if (c.N == N && c.L == L && c.S == S && c.nj == nj && c.used == ks.src.array_used && c.n_arrays == ks.src.n_arrays) hit = c;
+        }
+        if (hit.polys) {
+            HIP_TRY(hipMemcpyAsync(d_polys, hit.polys, sizeof(uint32_t) * 624 * (size_t)nj, hipMemcpyHostToDevice, stream));
+            HIP_TRY(hipMemcpyAsync(d_off, hit.offs, sizeof(uint64_t) * (size_t)nj, hipMemcpyHostToDevice, stream));
+        } else {
         static thread_local std::vector<uint64_t> offs;
         static thread_local std::vector<uint32_t> polys;
         offs.assign((size_t)nj, 0);
@@ -2326,13 +2354,30 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
                 return fail(-5, "%s", "MT19937 characteristic polynomial could not be derived");
             for (size_t q = 0; q < Js.size(); q++) memcpy(&polys[(size_t)where[q] * 624], &tmp[q * 624], 624 * sizeof(uint32_t));
         }
-        HIP_TRY(hipMemcpyAsync(d_polys, polys.data(), sizeof(uint32_t) * 624 * (size_t)nj, hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipMemcpyAsync(d_off, offs.data(), sizeof(uint64_t) * (size_t)nj, hipMemcpyHostToDevice, stream));
+        PlanCache c;
+        c.N = N; c.L = L; c.S = S; c.nj = nj; c.used = ks.src.array_used; c.n_arrays = ks.src.n_arrays;
+        c.polys = nullptr; c.offs = nullptr;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c.polys), sizeof(uint32_t) * 624 * (size_t)nj, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c.offs), sizeof(uint64_t) * (size_t)nj, hipHostMallocDefault));
+        memcpy(c.polys, polys.data(), sizeof(uint32_t) * 624 * (size_t)nj);
+        memcpy(c.offs, offs.data(), sizeof(uint64_t) * (size_t)nj);
+        HIP_TRY(hipMemcpyAsync(d_polys, c.polys, sizeof(uint32_t) * 624 * (size_t)nj, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(d_off, c.offs, sizeof(uint64_t) * (size_t)nj, hipMemcpyHostToDevice, stream));
+        {
+            std::lock_guard<std::mutex> lock(plan_mu);
+            if (plans.size() >= 64) {       // oldest plan out (its buffers may still be in flight: sync first)
+                (void)hipStreamSynchronize(stream);
+                (void)hipHostFree(plans.front().polys); (void)hipHostFree(plans.front().offs);
+                plans.erase(plans.begin());
+            }
+            plans.push_back(c);
+        }
+        }
         KJumpJobs jobs;
         jobs.polys = d_polys; jobs.offsets = d_off; jobs.dst = dst; jobs.n_jobs = nj; jobs.n_runs = n_runs;
         const size_t jl = sizeof(uint32_t) * ((size_t)XRT_STRETCH + 48 + 624);
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(xrt_jump_jobs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)jl));
-        int gy = (1024 + n_runs - 1) / n_runs;
+        int gy = (512 + n_runs - 1) / n_runs;
         if (gy > nj) gy = nj;
         if (gy < 1) gy = 1;
         hipLaunchKernelGGL(xrt_jump_jobs_kernel, dim3(n_runs, gy), dim3(XRT_JUMP_THREADS), jl, stream, streams, jobs);
