@@ -183,7 +183,7 @@ def main():
                        'num_out': {n: int(v) for n, v in zip(flat.names, num_out)}},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
-                         'kernel': 'xrt_trace_kernel<false, false>', 'kernel_ms_avg': kavg_s * 1e3,
+                         'kernel': 'xrt_trace_kernel<false, 0, false>', 'kernel_ms_avg': kavg_s * 1e3,
                          'algorithmic_bytes_per_photon': ALGO_BYTES_PER_PHOTON,
                          'photons_per_launch': per_launch_photons},
         }

@@ -1938,7 +1938,11 @@ static SegPlan plan_segments(const xrt_scene_t* sc, int n_runs)
     int want = 0;
     int64_t min_len = 4096;                     // below this the jump-ahead of a unit's heads outweighs its rays
     if (const char* e = getenv("XICSRT_SEGMENTS")) { want = atoi(e); min_len = XRT_TILE; }
-    else if (n_runs < 256) want = (512 + n_runs - 1) / n_runs;      // about two units per CU
+    else if (n_runs < 256) {
+        int target = 512;                       // about two units per CU
+        if (const char* t = getenv("XICSRT_TARGET_UNITS")) target = atoi(t) > 0 ? atoi(t) : target;
+        want = (target + n_runs - 1) / n_runs;
+    }
     if (want <= 1 || N < 2 * XRT_TILE || getenv("XICSRT_NO_JUMP")) return p;
     int64_t len = (N + want - 1) / want;
     if (len < min_len) len = min_len;
