@@ -958,27 +958,6 @@ __device__ __forceinline__ void hist_write(double* hist, uint8_t* hmask, int64_t
 // generator set-up kernels
 // --------------------------------------------------------------------------
 
-// np.random.seed(int) -> init_genrand, one thread per run (xicsrt_raytrace.py:111)
-__global__ void xrt_seed_kernel(const uint32_t* seeds, KStream* streams, KState* gauss_state, int n_runs)
-{
-    int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_runs) return;
-    gauss_state[r].has_gauss = 0;
-    gauss_state[r].gauss = 0.0;
-    uint32_t s = seeds[r];
-    KStream* st = streams + r;
-    for (int i = 0; i < 624; i++) {
-        st->ring[i] = s;
-        s = 1812433253u * (s ^ (s >> 30)) + (uint32_t)(i + 1);
-    }
-    // canonical form at kernel boundaries: 512 words generated ahead of `next`
-    // (what the propagation kernel leaves behind, and what the jump expects)
-    for (uint32_t n = 624; n < 624u + XRT_AHEAD; n++)
-        st->ring[n & XRT_RMASK] = mt_mix(st->ring[(n - 624u) & XRT_RMASK], st->ring[(n - 623u) & XRT_RMASK],
-                                         st->ring[(n - 227u) & XRT_RMASK]);
-    st->gen = 624 + XRT_AHEAD;
-    st->next = 624;
-}
 
 // explicit numpy state -> stream (xrt_trace_history)
 __global__ void xrt_import_state_kernel(const KState* in, KStream* out, KState* gauss_state)
@@ -1032,6 +1011,32 @@ __device__ __forceinline__ void wave_walk(uint32_t* ring, uint64_t& gen, uint64_
         wave_fence();
         gen = target;
     }
+}
+
+// np.random.seed(int) -> init_genrand (xicsrt_raytrace.py:111), one wave per run: lane 0 runs the
+// serial recurrence into LDS, the wave then generates the 512 words of the canonical form
+// (what the propagation kernel leaves behind, and what the jump expects) and stores the ring coalesced
+__global__ __launch_bounds__(64)
+void xrt_seed_kernel(const uint32_t* seeds, KStream* streams, KState* gauss_state, int n_runs)
+{
+    __shared__ uint32_t ring[XRT_RING];
+    const int r = blockIdx.x, lane = threadIdx.x;
+    if (r >= n_runs) return;
+    if (lane == 0) {
+        gauss_state[r].has_gauss = 0;
+        gauss_state[r].gauss = 0.0;
+        uint32_t s = seeds[r];
+        for (int i = 0; i < 624; i++) {
+            ring[i] = s;
+            s = 1812433253u * (s ^ (s >> 30)) + (uint32_t)(i + 1);
+        }
+    }
+    wave_fence();
+    uint64_t gen = 624;
+    wave_walk(ring, gen, 624ull + (uint64_t)XRT_AHEAD, lane);
+    KStream* st = streams + r;
+    for (int i = lane; i < (int)XRT_RING; i += 64) st->ring[i] = ring[i];
+    if (lane == 0) { st->gen = 624 + XRT_AHEAD; st->next = 624; }
 }
 
 __global__ __launch_bounds__(256)
@@ -2465,7 +2470,7 @@ extern "C" int xrt_trace(const xrt_scene_t* sc, const uint32_t* seeds, int32_t n
     uint32_t* d_seeds = reinterpret_cast<uint32_t*>(ws + ws_off_seeds(sc));
     KStream* streams = reinterpret_cast<KStream*>(ws + ws_off_streams(sc, n_runs));
     HIP_TRY(hipMemcpyAsync(d_seeds, seeds, sizeof(uint32_t) * (size_t)n_runs, hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(xrt_seed_kernel, dim3((n_runs + 63) / 64), dim3(64), 0, stream, d_seeds, streams,
+    hipLaunchKernelGGL(xrt_seed_kernel, dim3(n_runs), dim3(64), 0, stream, d_seeds, streams,
                        reinterpret_cast<KState*>(ws + ws_off_gauss(sc, n_runs)), n_runs);
     HIP_TRY(hipGetLastError());
     st = upload_tables(sc, ws, stream);
