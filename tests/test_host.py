@@ -206,3 +206,48 @@ def test_product_does_not_reference_the_oracle():
             if f.endswith(('.py', '.hip', '.h', '.sh')):
                 text = open(os.path.join(root, f)).read()
                 assert 'xrt_oracle' not in text and 'oracle/' not in text, f
+
+
+def test_import_xicsrt_compatibility_layout(tmp_path):
+    """compat.install(): `import xicsrt`, the upstream one-module-per-class names, and a user plug-in written
+    against the reference's imports resolves to device-backed classes."""
+    import sys
+    from xicsrt_amd import compat
+    for k in [k for k in sys.modules if k == 'xicsrt' or k.startswith('xicsrt.')]:
+        del sys.modules[k]
+    pkg = compat.install()
+    try:
+        import xicsrt
+        assert xicsrt is pkg and xicsrt.raytrace is xicsrt_amd.raytrace
+        from xicsrt import xicsrt_io as io2, xicsrt_config as cfg2, xicsrt_multiprocessing as mp2
+        assert io2 is xicsrt_amd.xicsrt_io and cfg2 is xconfig and mp2.raytrace is xrt.raytrace_mp
+        from xicsrt.optics._InteractCrystal import InteractCrystal
+        from xicsrt.optics._ShapeSphere import ShapeSphere
+        from xicsrt.optics._XicsrtOpticDetector import XicsrtOpticDetector
+        from xicsrt.sources._XicsrtSourceFocused import XicsrtSourceFocused
+        from xicsrt.objects._RayArray import RayArray
+        from xicsrt.filters._XicsrtBundleFilterSightline import XicsrtBundleFilterSightline
+        assert XicsrtOpticDetector is xrt.find_class('XicsrtOpticDetector', 'optics', [])
+        assert XicsrtSourceFocused.cone_axis_rule == 'target' and RayArray is xrt.RayArray
+        # a user plug-in in the reference's style: file _<ClassName>.py on general.pathlist
+        (tmp_path / '_XicsrtOpticMyCrystal.py').write_text('\n'.join([
+            'from xicsrt.optics._InteractCrystal import InteractCrystal',
+            'from xicsrt.optics._ShapeSphere import ShapeSphere',
+            'class XicsrtOpticMyCrystal(InteractCrystal, ShapeSphere):',
+            '    def default_config(self):',
+            '        config = super().default_config()',
+            '        config["radius"] = 1.0',
+            '        return config', '']))
+        cls = xrt.find_class('XicsrtOpticMyCrystal', 'optics', [str(tmp_path)])
+        assert issubclass(cls, InteractCrystal) and issubclass(cls, ShapeSphere)
+        cfg, gold = helpers.load_golden('C_sphere_trace')
+        cfg['general']['pathlist'] = [str(tmp_path)]
+        cfg['optics']['crystal']['class_name'] = 'XicsrtOpticMyCrystal'
+        config, elements, flat = helpers.build(cfg)
+        assert flat.struct.optics[0].shape == xscene.SHAPE['sphere']
+        with pytest.raises(ImportError):
+            sys.modules['xicsrt'] = __import__('json')      # something else owns the name
+            compat.install()
+    finally:
+        for k in [k for k in sys.modules if k == 'xicsrt' or k.startswith('xicsrt.')]:
+            del sys.modules[k]
