@@ -357,6 +357,29 @@ def build_cases():
     add('F_generic_plasma_trace', 'trace', cfg_three(0, sph, source=dict(box, class_name='XicsrtPlasmaGeneric',
                                                                         time_resolution=3e9), history=True, seed=69))
 
+    # --- the reference's own integrated tests (testing/integrated_test_01 / _02 .ipynb): one base config,
+    #     crystal class swapped, non-strict config check with keys that most classes do not know ------------
+    def integrated(radius, rmaj, rmin, fwhm, spread_deg, size, src_size, n):
+        return {'general': dict(_general(0), strict_config_check=False, save_images=False),
+                'sources': {'source': _source(n, spread_deg, xsize=src_size, ysize=src_size, zsize=0.0)},
+                'optics': {'crystal': dict(_crystal('XicsrtOpticPlanarMirror', xsize=size, ysize=size), radius=radius,
+                                           radius_major=rmaj, radius_minor=rmin, mesh_size=[41, 41],
+                                           crystal_spacing=2.45676, rocking_type='gaussian', rocking_fwhm=fwhm,
+                                           check_bragg=False),
+                           'detector': _detector()}}
+    for cls in ('PlanarMirror', 'SphericalMirror', 'PlanarCrystal', 'SphericalCrystal', 'CylindricalCrystal',
+                'ToroidalCrystal', 'MeshSphericalCrystal', 'MeshCylindricalCrystal', 'MeshToroidalCrystal',
+                'PlanarMosaicCrystal', 'SphericalMosaicCrystal'):
+        cfg = integrated(1.0, 1.0, 0.2, 48.070e-6, 10.0, 0.2, 0.0, 10000)
+        cfg['optics']['crystal']['class_name'] = 'XicsrtOptic' + cls
+        add('I1_' + cls, 'counts', cfg)
+    for cls in ('PlanarCrystal', 'SphericalCrystal', 'CylindricalCrystal', 'ToroidalCrystal',
+                'MeshSphericalCrystal', 'MeshCylindricalCrystal', 'MeshToroidalCrystal'):
+        cfg = integrated(1e5, 1e5, 0.5e5, 48.070e-5, 5.0, 0.1, 0.10, 2500)
+        cfg['general']['keep_history'] = True
+        cfg['optics']['crystal']['class_name'] = 'XicsrtOptic' + cls
+        add('I2_' + cls + '_trace', 'trace', cfg)
+
     # --- object-level API: generate_rays / trace_global / make_image on a caller's ray array ----
     add('O_object_sphere', 'object', cfg_three(4000, dict(sph, rocking_fwhm=2e-3), seed=91))
     add('O_object_mirror_local', 'object', cfg_three(3000, dict(mir, trace_local=True), seed=92))

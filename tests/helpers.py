@@ -131,6 +131,18 @@ def split_images(flat, images):
     return out
 
 
+# Float tolerance of the parity tests: 1e-12 relative (the task's bound is 1e-6).  One fixture needs more:
+# the reference's near-flat torus of testing/integrated_test_02 (radii 1e5 / 0.5e5 m) makes the quartic
+# ill-conditioned; its complex Ferrari/Cardano evaluation and the real-arithmetic restatement agree to
+# 1.6e-11 there (masks and counts are identical).
+RTOL_DEFAULT = 1e-12
+RTOL_CASE = {'I2_ToroidalCrystal_trace': 1e-9}
+
+
+def rtol_for(name):
+    return RTOL_CASE.get(name, RTOL_DEFAULT)
+
+
 def assert_history_matches_golden(flat, rays, mask, gold, rtol=1e-12):
     """
     Compare a device/oracle history snapshot with a golden 'trace' fixture:

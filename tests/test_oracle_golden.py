@@ -46,7 +46,7 @@ def test_trace_against_reference(name, oracle):
         assert int(num_out[k]) == int(gold['num_out/' + nm]), nm
     for nm, img in helpers.split_images(flat, images).items():
         assert np.array_equal(img, gold['image/' + nm]), 'image ' + nm
-    helpers.assert_history_matches_golden(flat, rays, mask, gold)
+    helpers.assert_history_matches_golden(flat, rays, mask, gold, rtol=helpers.rtol_for(name))
     assert helpers.state_next_double(st_out) == float(gold['next_double'])
 
 
