@@ -12,7 +12,7 @@ cfg['general'].update(number_of_runs=runs, random_seed=0)
 config, elements, flat = helpers.build(cfg)
 seeds = xrt.run_seeds(0, runs)
 dev = xrt.DeviceTrace(flat)
-dev.trace(seeds[:8], 1); dev.results()
+dev.trace(seeds, 1); dev.results()              # warm-up with the full run count: allocates the workspace
 dev.num_out.zero_(); dev.images.zero_()
 t0 = time.time(); dev.trace(seeds, 1); meta, image = dev.results(); dt = time.time() - t0
 n = int(meta['source']['num_out'])

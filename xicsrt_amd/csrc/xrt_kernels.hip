@@ -1882,9 +1882,9 @@ static bool needs_staged(const xrt_scene_t* sc)
 // ray arrays of a scene would take more than XRT_ST_BUDGET bytes of workspace in total.
 #define XRT_ST_SLOTS 256
 #define XRT_ST_BUDGET (64ull << 30)
-static int staged_slots_for(int n_runs, size_t per_slot_bytes)
+static int staged_slots_for(int n_runs, size_t per_slot_bytes, int per_cu)
 {
-    size_t s = XRT_ST_SLOTS;
+    size_t s = (size_t)XRT_ST_SLOTS * (size_t)per_cu;
     if (per_slot_bytes > 0 && s * per_slot_bytes > XRT_ST_BUDGET) s = XRT_ST_BUDGET / per_slot_bytes;
     if (s < 1) s = 1;
     if ((size_t)n_runs < s) s = (size_t)(n_runs < 1 ? 1 : n_runs);
@@ -1923,9 +1923,13 @@ static size_t staged_slot_bytes(const xrt_scene_t* sc)
 {
     const size_t n = (size_t)(sc->source.intensity > 0 ? sc->source.intensity : 1);
     const size_t nb = (size_t)(sc->source.bundle_count > 0 ? sc->source.bundle_count : 0);
-    return n * (XRT_ST_ARRAYS * sizeof(double) + 2 * sizeof(uint32_t)) + nb * XRT_ST_BUNDLE_ROWS * sizeof(double);
+    return n * (XRT_ST_ARRAYS * sizeof(double) + 2 * sizeof(uint32_t)) + nb * XRT_ST_BUNDLE_ROWS * sizeof(double) + 16;
 }
-static int staged_slots(const xrt_scene_t* sc, int n_runs) { return staged_slots_for(n_runs, staged_slot_bytes(sc)); }
+// plasma scenes run source and optics as separate launches over batches of 4 x 256 run slots
+static int staged_slots(const xrt_scene_t* sc, int n_runs)
+{
+    return staged_slots_for(n_runs, staged_slot_bytes(sc), sc->source.kind == XRT_SRC_PLASMA ? 4 : 1);
+}
 static size_t staged_bytes(const xrt_scene_t* sc, int n_runs)
 {
     if (!needs_staged(sc)) return 0;
@@ -2301,8 +2305,30 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
         for (int e = 0; e < sc->n_optics; e++)
             special = special || sc->optics[e].interact == XRT_INTERACT_MOSAIC || sc->optics[e].shape == XRT_SHAPE_MESH ||
                       (sc->optics[e].flags & XRT_F_TRACE_LOCAL);
-        void (*kern)(const KScene, const KArgs, const KStaged);
         if (src == 2 && !hist) return fail(-2, "%s", "external rays are traced through xrt_trace_history");
+        static const bool no_split = getenv("XICSRT_NO_STAGE_SPLIT") != nullptr;
+        if (src == 1 && !hist && !no_split) {
+            // plasma: source and optics in separate launches, a batch of `slots` runs at a time
+            g.n_src_slot = reinterpret_cast<int64_t*>(g.bundle_off + (size_t)slots * XRT_ST_BUNDLE_ROWS * (size_t)(sc->source.bundle_count > 0 ? sc->source.bundle_count : 0));
+            void (*k1)(const KScene, const KArgs, const KStaged) = xrt_staged_kernel<false, 1, false, 1>;
+            void (*k2)(const KScene, const KArgs, const KStaged) = special ? xrt_staged_kernel<false, 1, true, 2>
+                                                                           : xrt_staged_kernel<false, 1, false, 2>;
+            for (int base_run = 0; base_run < n_runs; base_run += slots) {
+                const int nb = (n_runs - base_run) < slots ? (n_runs - base_run) : slots;
+                g.run_base = base_run;
+                a.n_runs = nb;
+                int grid1 = nb < 768 ? nb : 768, grid2 = nb < 256 ? nb : 256;       // three source workgroups, one optics workgroup per CU
+                HIP_TRY(hipMemsetAsync(ws, 0, 64, stream));
+                hipLaunchKernelGGL(k1, dim3(grid1), dim3(XRT_TILE), lds, stream, ks, a, g);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipMemsetAsync(ws, 0, 64, stream));
+                hipLaunchKernelGGL(k2, dim3(grid2), dim3(XRT_TILE), lds, stream, ks, a, g);
+                HIP_TRY(hipGetLastError());
+            }
+            if (ti >= 0) HIP_TRY(hipEventRecord(timing_ev[ti][1], stream));
+            return 0;
+        }
+        void (*kern)(const KScene, const KArgs, const KStaged);
         if (hist) kern = src == 2 ? (special ? xrt_staged_kernel<true, 2, true> : xrt_staged_kernel<true, 2, false>)
                        : src == 1 ? (special ? xrt_staged_kernel<true, 1, true> : xrt_staged_kernel<true, 1, false>)
                                   : (special ? xrt_staged_kernel<true, 0, true> : xrt_staged_kernel<true, 0, false>);
