@@ -243,3 +243,14 @@ def test_integrated_test_00_photon_accounting():
     # keep_history defaults to True: found + lost histories hold every ray of the run
     n_found = len(results['found']['history']['detector']['mask'])
     assert n_found == num_act_detector and results['found']['history']['source']['origin'].shape == (n_found, 3)
+
+
+@pytest.mark.gpu
+def test_plasma_errors_surface_as_the_references_value_errors():
+    """Per-bundle conditions only the device can see come back as the reference's ValueError."""
+    import xicsrt_amd
+    cfg, gold = helpers.load_golden('F_datafile_trace')
+    cfg['sources']['source'].update(use_poisson=False)         # some bundle has intensity < 1
+    cfg['general'].update(keep_history=False)
+    with pytest.raises(ValueError, match='intensity of less than one encountered'):
+        xicsrt_amd.raytrace(cfg)

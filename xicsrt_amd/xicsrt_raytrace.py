@@ -283,8 +283,12 @@ class DeviceTrace:
     def results(self):
         """Host copies (synchronises the stream): num_out list, {optic: image or None}."""
         if self._ws is not None:
-            self.capi.check(self.lib.xrt_check(self._ws.data_ptr(), self.torch.cuda.current_stream().cuda_stream),
-                            'xrt_check')
+            status = self.lib.xrt_check(self._ws.data_ptr(), self.torch.cuda.current_stream().cuda_stream)
+            if status in (-6, -7):
+                # conditions the reference reports with ValueError while it builds the bundle sources
+                # (_XicsrtSourceGeneric.py:193-194, _XicsrtPlasmaGeneric.py:277-281)
+                raise ValueError(self.lib.xrt_last_error().decode())
+            self.capi.check(status, 'xrt_check')
         self.torch.cuda.current_stream().synchronize()
         return self.unpack(self.num_out.cpu().numpy(), self.images.cpu().numpy())
 
