@@ -249,11 +249,12 @@ class DeviceTrace:
                                 ws.data_ptr(), need, stream)
         self.capi.check(st, 'xrt_trace')
 
-    def trace_history(self, state, keep_images=True, all_rays=False):
+    def trace_history(self, state, keep_images=True, all_rays=False, on_device=False):
         """
         One iteration from an explicit MT19937 state (key, pos, has_gauss, gauss).
         Returns (rays[n_el, 8, N] float64, mask[n_el, N] bool, state_out) on the host.
         `all_rays`: keep rays whose source mask is off (caller-supplied ray arrays).
+        `on_device`: return the device tensors (rays [n_el, 8, capacity], mask uint8) without the big copy.
         """
         t = self.torch
         n, ne = self.flat.n_rays, self.flat.n_elements
@@ -275,6 +276,8 @@ class DeviceTrace:
         t.cuda.current_stream().synchronize()
         out = xscene.RngState.from_buffer_copy(st_out.cpu().numpy().tobytes())
         state_out = (np.ctypeslib.as_array(out.key).copy(), int(out.pos), int(out.has_gauss), float(out.gauss))
+        if on_device:
+            return rays, mask, state_out
         mask_h = mask.cpu().numpy()[:, :n].astype(bool)
         if not all_rays:
             n = int(mask_h[0].sum())    # plasma sources: the ray count is drawn, n_rays is the capacity
@@ -374,6 +377,35 @@ def _sort_history(history, rng, max_lost):
     return found, lost
 
 
+def _sorted_history_from_device(elements, device, d_rays, d_mask, rng, max_lost):
+    """
+    _sort_raytrace (xicsrt_raytrace.py:229-278) without moving every ray to the host: the masks come
+    over (one byte per ray and element), the found rays and the reference's shuffled sample of at most
+    `max_lost` lost rays are chosen exactly as _sort_history does (same draws from `rng`), and only those
+    rays are gathered on the device and copied.  Per-ray results are independent, so this equals
+    _history_from_device + _sort_history on the full arrays.
+    """
+    t = device.torch
+    mask_all = d_mask.cpu().numpy().astype(bool)
+    n = int(mask_all[0].sum())            # plasma sources: the ray count is drawn, the arrays hold the capacity
+    mask_h = mask_all[:, :n]
+    last = mask_h[-1]
+    w_found = np.flatnonzero(last)
+    w_lost = np.flatnonzero(np.invert(last))
+    max_lost = min(max_lost, len(w_lost))
+    index_lost = np.arange(len(w_lost))
+    rng.shuffle(index_lost)
+    w_lost = w_lost[index_lost[:max_lost]]
+    sel = np.concatenate([w_found, w_lost]).astype(np.int64)
+    d_sel = t.from_numpy(sel).to(d_rays.device)
+    rays_sel = d_rays.index_select(2, d_sel).cpu().numpy()
+    history = _history_from_device(elements.names, rays_sel, mask_h[:, sel], elements.optics)
+    nf = len(w_found)
+    found = {key: {k: v[:nf] for k, v in history[key].items()} for key in history}
+    lost = {key: {k: v[nf:] for k, v in history[key].items()} for key in history}
+    return found, lost
+
+
 def combine_raytrace(input_list, keep_images=True, components=None):
     """Combine result dictionaries: sum meta and images, concatenate histories."""
     output = _empty_output(input_list[0]['config'])
@@ -466,10 +498,10 @@ def _run_with_history(config, elements, device, seed, max_lost_iter):
     outputs = []
     for _ in range(general['number_of_iter']):
         st = rng.get_state()
-        rays, mask, state_out = device.trace_history((st[1], st[2], st[3], st[4]), general['keep_images'])
+        d_rays, d_mask, state_out = device.trace_history((st[1], st[2], st[3], st[4]), general['keep_images'],
+                                                         on_device=True)
         _advance(rng, state_out)
-        history = _history_from_device(elements.names, rays, mask, elements.optics)
-        found, lost = _sort_history(history, rng, max_lost_iter)
+        found, lost = _sorted_history_from_device(elements, device, d_rays, d_mask, rng, max_lost_iter)
         single = _empty_output(config)
         # totals are accumulated on the device and filled in by the caller
         single['total']['meta'] = {name: {'num_out': 0} for name in elements.names}
