@@ -1013,6 +1013,22 @@ __device__ __forceinline__ void wave_walk(uint32_t* ring, uint64_t& gen, uint64_
     }
 }
 
+// An imported generator state (np.random.get_state(): block of 624 words + position) brought to the form
+// the jump-ahead wants: exactly 624 words generated ahead of `next`, i.e. `pos` more words are generated.
+__global__ __launch_bounds__(64)
+void xrt_advance_kernel(KStream* st)
+{
+    __shared__ uint32_t ring[XRT_RING];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < (int)XRT_RING; i += 64) ring[i] = st->ring[i];
+    uint64_t gen = uni64(st->gen);
+    const uint64_t next = uni64(st->next);
+    wave_fence();
+    wave_walk(ring, gen, next + 624ull, lane);
+    for (int i = lane; i < (int)XRT_RING; i += 64) st->ring[i] = ring[i];
+    if (lane == 0) st->gen = gen;
+}
+
 // np.random.seed(int) -> init_genrand (xicsrt_raytrace.py:111), one wave per run: lane 0 runs the
 // serial recurrence into LDS, the wave then generates the 512 words of the canonical form
 // (what the propagation kernel leaves behind, and what the jump expects) and stores the ring coalesced
@@ -1224,6 +1240,7 @@ struct KJumpJobs {
     const uint64_t* offsets;    // [n_jobs] words from the stream head's `next`
     KStream* dst;               // [n_runs][n_jobs]
     int32_t n_jobs, n_runs;
+    uint64_t ahead;             // words the stream heads have generated ahead of `next` (512, or 624 for imported states)
 };
 
 __global__ __launch_bounds__(XRT_JUMP_THREADS)
@@ -1245,7 +1262,7 @@ void xrt_jump_jobs_kernel(const KStream* streams, const KJumpJobs jobs)
             KStream* out = jobs.dst + (size_t)run * jobs.n_jobs + j;
             const uint64_t off = jobs.offsets[j];
             const uint64_t target = next + off;
-            if (off < (uint64_t)XRT_AHEAD) {
+            if (off < jobs.ahead) {
                 if (tid < (int)XRT_RING) out->ring[tid] = st->ring[tid];
                 if (tid == 0) { out->gen = gen; out->next = target; }
                 continue;
@@ -1303,7 +1320,6 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
 {
     constexpr bool FULL = VARIANT >= 1;
     constexpr bool EXT = VARIANT == 2;
-    static_assert(!(SEG && HIST), "history is kept by unsegmented runs");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     // One circular structure-of-arrays buffer of XRT_QCAP ray records serves as
     //  (a) the FIFO queue of rays waiting for the Bragg test (filled tile by tile in ray
@@ -1496,7 +1512,7 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
                                 hit = h.hit != 0; X.x = h.x; X.y = h.y; X.z = h.z; aux = h.aux;
                             } else hit = intersect_point<FULL>(op, ray, X);
                             alive = hit && check_bounds<FULL>(op, X);
-                            if (HIST && !alive) {
+                            if (HIST && !alive && !counting) {
                                 V3 xo = X, dd = ray.d;
                                 if (!hit) { xo.x = xo.y = xo.z = __builtin_nan(""); }
                                 if (local) {
@@ -1522,13 +1538,13 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
                                 ray.o.x += op.origin[0]; ray.o.y += op.origin[1]; ray.o.z += op.origin[2];
                                 ray.d = to_external(op.R, ray.d);
                             }
-                            if (HIST) hist_write(args.hist, args.hmask, N, e + 1, id, ray.o, ray.d, ray.wl, true);
+                            if (HIST && !counting) hist_write(args.hist, args.hmask, N, e + 1, id, ray.o, ray.d, ray.wl, true);
                         }
                     } else {
                         if (have) {
                             bool hit = intersect_point<FULL>(op, ray, X);
                             alive = hit && check_bounds<FULL>(op, X);
-                            if (HIST && !alive) {
+                            if (HIST && !alive && !counting) {
                                 V3 xo = X;
                                 if (!hit) { xo.x = xo.y = xo.z = __builtin_nan(""); }
                                 hist_write(args.hist, args.hmask, N, e + 1, id, xo, ray.d, ray.wl, false);
@@ -1545,7 +1561,7 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
                                 ray.d.y = ray.d.y - 2.0 * (dt * nrm.y);
                                 ray.d.z = ray.d.z - 2.0 * (dt * nrm.z);
                             }
-                            if (HIST) hist_write(args.hist, args.hmask, N, e + 1, id, ray.o, ray.d, ray.wl, true);
+                            if (HIST && !counting) hist_write(args.hist, args.hmask, N, e + 1, id, ray.o, ray.d, ray.wl, true);
                         }
                     }
                 }
@@ -1608,7 +1624,7 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
             bool have = (uint32_t)tid < n_tile, alive = false;
             source_ray<FULL>(S, u, ray);
             if (tid == 0 && !counting) cnt[0] += n_tile;
-            if (HIST && have) hist_write(args.hist, args.hmask, N, 0, id, ray.o, ray.d, ray.wl, true);
+            if (HIST && have && !counting) hist_write(args.hist, args.hmask, N, 0, id, ray.o, ray.d, ray.wl, true);
 
             // elements in config order (objects/_Dispatcher.py:166-196) up to the Bragg element
             if (counting) {
@@ -2268,9 +2284,12 @@ static int launch_variant(const KScene& ks, const KArgs& a, int n_runs, size_t l
 
 // one iteration of every run: position the heads (jump-ahead when every stream is in the
 // canonical form and the arrays are long enough, else the sequential walk), then propagate
+// `ahead`: words every stream head has generated beyond `next` when this is called (XRT_AHEAD: the
+// canonical form between kernels; 624: an imported state after xrt_advance_kernel; 0: unknown)
 static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArgs a, int n_runs, bool hist,
-                         bool canonical, hipStream_t stream)
+                         int ahead, hipStream_t stream)
 {
+    const bool canonical = ahead == (int)XRT_AHEAD;
     const int nh = count_heads(sc);
     KStream* streams = reinterpret_cast<KStream*>(ws + ws_off_streams(sc, n_runs));
     KStream* heads = reinterpret_cast<KStream*>(ws + ws_off_heads(sc, n_runs));
@@ -2339,7 +2358,7 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
         if (ti >= 0) HIP_TRY(hipEventRecord(timing_ev[ti][1], stream));
         return 0;
     }
-    const SegPlan plan = (canonical && !hist) ? plan_segments(sc, n_runs) : SegPlan{1, 0};
+    const SegPlan plan = ahead > 0 ? plan_segments(sc, n_runs) : SegPlan{1, 0};
     if (plan.n_seg > 1) {
         // ---- segmented runs -------------------------------------------------------------------------
         const int S = plan.n_seg, nj = seg_jobs(sc, plan);
@@ -2354,7 +2373,7 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
         uint32_t* d_cnt = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(d_off) + al256(sizeof(uint64_t) * (size_t)nj));
         // jobs of a run: [segment][source head], then the chunk heads, then the stream head behind the arrays
         // polynomials + offsets of a plan live in pinned host memory and are reused by later calls
-        struct PlanCache { int64_t N, L; int S, nj; uint32_t used; int n_arrays; uint32_t* polys; uint64_t* offs; };
+        struct PlanCache { int64_t N, L; int S, nj; uint32_t used; int n_arrays, ahead; uint32_t* polys; uint64_t* offs; };
         static std::mutex plan_mu;
         static std::vector<PlanCache> plans;
         PlanCache hit;
@@ -2362,7 +2381,8 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
         {
             std::lock_guard<std::mutex> lock(plan_mu);
             for (const PlanCache& c : plans)
-                if (c.N == N && c.L == L && c.S == S && c.nj == nj && c.used == ks.src.array_used && c.n_arrays == ks.src.n_arrays) hit = c;
+                if (c.N == N && c.L == L && c.S == S && c.nj == nj && c.used == ks.src.array_used && c.n_arrays == ks.src.n_arrays &&
+                    c.ahead == ahead) hit = c;
         }
         if (hit.polys) {
             HIP_TRY(hipMemcpyAsync(d_polys, hit.polys, sizeof(uint32_t) * 624 * (size_t)nj, hipMemcpyHostToDevice, stream));
@@ -2383,14 +2403,14 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
         {
             std::vector<uint64_t> Js;
             std::vector<int> where;
-            for (int q = 0; q < nj; q++) if (offs[q] >= (uint64_t)XRT_AHEAD) { Js.push_back(offs[q] - (uint64_t)XRT_AHEAD); where.push_back(q); }
+            for (int q = 0; q < nj; q++) if (offs[q] >= (uint64_t)ahead) { Js.push_back(offs[q] - (uint64_t)ahead); where.push_back(q); }
             std::vector<uint32_t> tmp(Js.size() * 624);
             if (!mtjump::jump_polys(Js.data(), (int)Js.size(), tmp.data()))
                 return fail(-5, "%s", "MT19937 characteristic polynomial could not be derived");
             for (size_t q = 0; q < Js.size(); q++) memcpy(&polys[(size_t)where[q] * 624], &tmp[q * 624], 624 * sizeof(uint32_t));
         }
         PlanCache c;
-        c.N = N; c.L = L; c.S = S; c.nj = nj; c.used = ks.src.array_used; c.n_arrays = ks.src.n_arrays;
+        c.N = N; c.L = L; c.S = S; c.nj = nj; c.used = ks.src.array_used; c.n_arrays = ks.src.n_arrays; c.ahead = ahead;
         c.polys = nullptr; c.offs = nullptr;
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c.polys), sizeof(uint32_t) * 624 * (size_t)nj, hipHostMallocDefault));
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c.offs), sizeof(uint64_t) * (size_t)nj, hipHostMallocDefault));
@@ -2410,6 +2430,7 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
         }
         KJumpJobs jobs;
         jobs.polys = d_polys; jobs.offsets = d_off; jobs.dst = dst; jobs.n_jobs = nj; jobs.n_runs = n_runs;
+        jobs.ahead = (uint64_t)ahead;
         const size_t jl = sizeof(uint32_t) * ((size_t)XRT_STRETCH + 48 + 624);
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(xrt_jump_jobs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)jl));
         int gy = (512 + n_runs - 1) / n_runs;
@@ -2426,9 +2447,13 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
         for (int mode = (be >= 0 ? 1 : 2); mode <= 2; mode++) {
             a.mode = mode;
             HIP_TRY(hipMemsetAsync(ws, 0, 64, stream));
-            int st = variant == 2 ? launch_variant<false, 2, true>(ks, a, n_runs, lds, stream)
-                   : variant == 1 ? launch_variant<false, 1, true>(ks, a, n_runs, lds, stream)
-                                  : launch_variant<false, 0, true>(ks, a, n_runs, lds, stream);
+            int st;
+            if (hist) st = variant == 2 ? launch_variant<true, 2, true>(ks, a, n_runs, lds, stream)
+                         : variant == 1 ? launch_variant<true, 1, true>(ks, a, n_runs, lds, stream)
+                                        : launch_variant<true, 0, true>(ks, a, n_runs, lds, stream);
+            else      st = variant == 2 ? launch_variant<false, 2, true>(ks, a, n_runs, lds, stream)
+                         : variant == 1 ? launch_variant<false, 1, true>(ks, a, n_runs, lds, stream)
+                                        : launch_variant<false, 0, true>(ks, a, n_runs, lds, stream);
             if (st) return st;
         }
         return 0;
@@ -2515,7 +2540,7 @@ extern "C" int xrt_trace(const xrt_scene_t* sc, const uint32_t* seeds, int32_t n
     // iterations share each run's stream (xicsrt_raytrace.py:153): the stream head left by
     // iteration i is where iteration i+1 starts
     for (int it = 0; it < n_iter; it++) {
-        st = run_iteration(sc, ks, ws, a, n_runs, false, true, stream);
+        st = run_iteration(sc, ks, ws, a, n_runs, false, (int)XRT_AHEAD, stream);
         if (st) return st;
     }
     return 0;
@@ -2553,7 +2578,14 @@ extern "C" int xrt_trace_history(const xrt_scene_t* sc, const xrt_rng_state_t* s
     a.num_out = reinterpret_cast<unsigned long long*>(num_out);
     a.images = reinterpret_cast<unsigned long long*>(images);
     a.hist = rays; a.hmask = mask;
-    st = run_iteration(sc, ks, ws, a, 1, true, false, stream);
+    int ahead = 0;
+    if (plan_segments(sc, 1).n_seg > 1) {
+        // segmented history run: the imported state gets the fixed lead the jump polynomials are made for
+        hipLaunchKernelGGL(xrt_advance_kernel, dim3(1), dim3(64), 0, stream, streams);
+        HIP_TRY(hipGetLastError());
+        ahead = 624;
+    }
+    st = run_iteration(sc, ks, ws, a, 1, true, ahead, stream);
     if (st) return st;
     if (state_out) {
         hipLaunchKernelGGL(xrt_export_state_kernel, dim3(1), dim3(64), 0, stream, streams,
