@@ -1941,10 +1941,10 @@ static size_t staged_slot_bytes(const xrt_scene_t* sc)
     const size_t nb = (size_t)(sc->source.bundle_count > 0 ? sc->source.bundle_count : 0);
     return n * (XRT_ST_ARRAYS * sizeof(double) + 2 * sizeof(uint32_t)) + nb * XRT_ST_BUNDLE_ROWS * sizeof(double) + 16;
 }
-// plasma scenes run source and optics as separate launches over batches of 4 x 256 run slots
+// source and optics run as separate launches over batches of up to 4 x 256 run slots
 static int staged_slots(const xrt_scene_t* sc, int n_runs)
 {
-    return staged_slots_for(n_runs, staged_slot_bytes(sc), sc->source.kind == XRT_SRC_PLASMA ? 4 : 1);
+    return staged_slots_for(n_runs, staged_slot_bytes(sc), sc->source.kind == XRT_SRC_EXTERNAL ? 1 : 4);
 }
 static size_t staged_bytes(const xrt_scene_t* sc, int n_runs)
 {
@@ -2326,12 +2326,14 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
                       (sc->optics[e].flags & XRT_F_TRACE_LOCAL);
         if (src == 2 && !hist) return fail(-2, "%s", "external rays are traced through xrt_trace_history");
         static const bool no_split = getenv("XICSRT_NO_STAGE_SPLIT") != nullptr;
-        if (src == 1 && !hist && !no_split) {
-            // plasma: source and optics in separate launches, a batch of `slots` runs at a time
+        if (src != 2 && !hist && !no_split) {
+            // source and optics in separate launches, a batch of `slots` runs at a time
             g.n_src_slot = reinterpret_cast<int64_t*>(g.bundle_off + (size_t)slots * XRT_ST_BUNDLE_ROWS * (size_t)(sc->source.bundle_count > 0 ? sc->source.bundle_count : 0));
-            void (*k1)(const KScene, const KArgs, const KStaged) = xrt_staged_kernel<false, 1, false, 1>;
-            void (*k2)(const KScene, const KArgs, const KStaged) = special ? xrt_staged_kernel<false, 1, true, 2>
-                                                                           : xrt_staged_kernel<false, 1, false, 2>;
+            void (*k1)(const KScene, const KArgs, const KStaged) = src == 1 ? xrt_staged_kernel<false, 1, false, 1>
+                                                                            : xrt_staged_kernel<false, 0, false, 1>;
+            void (*k2)(const KScene, const KArgs, const KStaged) =
+                src == 1 ? (special ? xrt_staged_kernel<false, 1, true, 2> : xrt_staged_kernel<false, 1, false, 2>)
+                         : (special ? xrt_staged_kernel<false, 0, true, 2> : xrt_staged_kernel<false, 0, false, 2>);
             for (int base_run = 0; base_run < n_runs; base_run += slots) {
                 const int nb = (n_runs - base_run) < slots ? (n_runs - base_run) : slots;
                 g.run_base = base_run;
