@@ -385,6 +385,8 @@ __device__ __forceinline__ void source_ray(const KSource& s, const double* u, Ra
     } else if (FULL && s.wavelength_dist == XRT_WL_VOIGT) {
         double y = s.wl_a + s.wl_b * u[5];
         wl = np_interp(y, s.voigt_cdf, s.voigt_x, s.voigt_n) + s.wavelength;
+    } else if (FULL && s.wavelength_dist == XRT_WL_NORMAL) {
+        wl = u[5];                      // np.random.normal(wavelength, sigma) value, prepared per ray
     } else {
         wl = 1.0 * s.wavelength;
     }
@@ -1300,6 +1302,10 @@ struct KArgs {
     const KStream* chunk_heads;         // per run n_seg stream heads, chunk_words apart, from the first Bragg uniform on
     int64_t  chunk_words;
     int64_t  run_stride;                // SEG: heads / chunk_heads of consecutive runs are this many KStreams apart
+    // Gaussian wavelengths (np.random.normal) prepared by xrt_gauss_kernel: the values per run and ray, and
+    // the words the rejection sampler consumed in front of the Bragg uniforms (null: none)
+    const double*   wl_array;           // [n_runs][n_rays]
+    const uint64_t* base_words;         // [n_runs]
 };
 
 #ifndef XRT_WAVES_PER_EU
@@ -1318,8 +1324,9 @@ template <bool HIST, int VARIANT, bool SEG>
 __global__ __launch_bounds__(XRT_TILE, (VARIANT == 2 ? 2 : XRT_WAVES_PER_EU))
 void xrt_trace_kernel(const KScene sc, const KArgs args)
 {
-    constexpr bool FULL = VARIANT >= 1;
+    constexpr bool FULL = VARIANT == 1 || VARIANT == 2;
     constexpr bool EXT = VARIANT == 2;
+    constexpr bool LEANWL = VARIANT == 3;       // the lean geometry with a prepared wavelength per ray
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     // One circular structure-of-arrays buffer of XRT_QCAP ray records serves as
     //  (a) the FIFO queue of rays waiting for the Bragg test (filled tile by tile in ray
@@ -1399,24 +1406,25 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
         // Bragg uniform, which lies 2 * (candidates of the earlier segments) words into the draws
         uint64_t seg_skip = 0;
         const KStream* st_in = st;
-        if (SEG && args.mode == 2 && be >= 0) {
-            // candidates of the earlier segments of this run, summed by the whole workgroup
-            if (tid == 0) cnt[0] = 0ULL;
-            __syncthreads();
-            unsigned long long part = 0;
-            for (uint32_t q = (uint32_t)tid; q < seg; q += XRT_TILE) part += args.unit_count[(size_t)run * args.n_seg + q];
-            if (part) atomicAdd(&cnt[0], part);
-            __syncthreads();
-            const uint64_t before = uni64(cnt[0]);
-            __syncthreads();
-            const uint64_t words = 2ull * before;
+        if (SEG && args.mode == 2 && (be >= 0 || seg + 1u == (uint32_t)args.n_seg)) {
+            // with a Bragg optic: the candidates of the earlier segments of this run, summed by the whole
+            // workgroup; without one only the last segment needs the stream (to store the run's new head).
+            // The draws start behind the source arrays (+ the words a Gaussian wavelength array consumed).
+            unsigned long long before = 0;
+            if (be >= 0) {
+                if (tid == 0) cnt[0] = 0ULL;
+                __syncthreads();
+                unsigned long long part = 0;
+                for (uint32_t q = (uint32_t)tid; q < seg; q += XRT_TILE) part += args.unit_count[(size_t)run * args.n_seg + q];
+                if (part) atomicAdd(&cnt[0], part);
+                __syncthreads();
+                before = uni64(cnt[0]);
+                __syncthreads();
+            }
+            const uint64_t words = 2ull * before + (args.base_words ? uni64(args.base_words[run]) : 0ull);
             const uint64_t chunk = words / (uint64_t)args.chunk_words;
             seg_skip = words - chunk * (uint64_t)args.chunk_words;
             st_in = args.chunk_heads + (size_t)run * args.run_stride + chunk;
-        } else if (SEG && args.mode == 2 && be < 0 && seg + 1u == (uint32_t)args.n_seg) {
-            // no Bragg draws: the run's stream ends right behind the source arrays; the last segment brings
-            // that head (positioned by the jump, behind the chunk heads) into the canonical form and stores it
-            st_in = args.chunk_heads + (size_t)run * args.run_stride + args.n_seg;
         }
         for (int i = tid; i < (int)XRT_RING; i += XRT_TILE) stream[i] = st_in->ring[i];
         const uint64_t s_next0 = uni64(st_in->next), s_gen0 = uni64(st_in->gen);
@@ -1622,7 +1630,11 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
             uint32_t id = (uint32_t)(i0 + tid);
             int aux = 0;
             bool have = (uint32_t)tid < n_tile, alive = false;
+            if constexpr (SEG && FULL) {
+                if (args.wl_array) u[5] = have ? args.wl_array[(size_t)run * (size_t)N + (size_t)id] : 0.0;
+            }
             source_ray<FULL>(S, u, ray);
+            if constexpr (SEG && LEANWL) ray.wl = have ? args.wl_array[(size_t)run * (size_t)N + (size_t)id] : 0.0;
             if (tid == 0 && !counting) cnt[0] += n_tile;
             if (HIST && have && !counting) hist_write(args.hist, args.hmask, N, 0, id, ray.o, ray.d, ray.wl, true);
 
@@ -1751,6 +1763,104 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
 }
 
 #include "xrt_staged.inc"
+
+
+// --------------------------------------------------------------------------
+// Gaussian wavelengths for the fused path: np.random.normal(loc, sigma, N) of every run, prepared
+// as an array.  numpy's legacy gauss is the polar method: candidate pairs (two doubles each) are
+// rejected unless 0 < r2 < 1, an accepted pair yields two values (f*x2 first, the cached f*x1 next),
+// so the stream consumption is data dependent.  The candidate stream of a run (it starts right
+// behind the source's uniform arrays) is cut into chunks with jump-positioned heads; mode 1 counts
+// the accepted pairs of every chunk, mode 2 writes the values of its chunk at the indices the counts
+// of the earlier chunks give, and the chunk that holds the last needed pair records how many words
+// the draws consumed (the Bragg uniforms follow there).  N is even and no value is cached on entry
+// (the host falls back to the staged path otherwise).
+// --------------------------------------------------------------------------
+struct KGauss {
+    const KStream* heads;       // chunk g of run r: heads[r * run_stride + g]
+    int64_t  run_stride;
+    int64_t  pairs_per_chunk;   // candidate pairs per chunk (a chunk is 4x as many words)
+    int64_t  n_values;          // N
+    int32_t  n_chunks, n_runs, mode, pad;
+    uint32_t* acc;              // [n_runs][n_chunks] accepted pairs per chunk
+    double*  wl;                // [n_runs][N]
+    uint64_t* end_words;        // [n_runs]
+    double   loc, sigma;
+    uint32_t* counter;
+    uint32_t* flags;            // bit 2: the provisioned candidates did not yield N values
+};
+
+__global__ __launch_bounds__(XRT_TILE)
+void xrt_gauss_kernel(const KGauss g)
+{
+    __shared__ uint32_t ring[XRT_RING];
+    __shared__ uint32_t wave_tot[16];
+    __shared__ unsigned long long sum64;
+    __shared__ uint32_t bcast;
+    const int tid = threadIdx.x;
+    int slot = 0;
+    const int64_t need_pairs = g.n_values / 2;
+    for (;;) {
+        if (tid == 0) bcast = atomicAdd(g.counter, 1u);
+        __syncthreads();
+        const uint32_t unit = uni32(bcast);
+        if (unit >= (uint32_t)g.n_runs * (uint32_t)g.n_chunks) break;
+        const uint32_t run = unit / (uint32_t)g.n_chunks, c = unit - run * (uint32_t)g.n_chunks;
+        // accepted pairs in the earlier chunks of this run
+        unsigned long long prefix = 0;
+        if (g.mode == 2 && g.n_chunks > 1) {
+            if (tid == 0) sum64 = 0ULL;
+            __syncthreads();
+            unsigned long long part = 0;
+            for (uint32_t q = (uint32_t)tid; q < c; q += XRT_TILE) part += g.acc[(size_t)run * g.n_chunks + q];
+            if (part) atomicAdd(&sum64, part);
+            __syncthreads();
+            prefix = uni64(sum64);
+        }
+        __syncthreads();
+        if (g.mode == 2 && (int64_t)prefix >= need_pairs) continue;        // every value lies in earlier chunks
+        const KStream* h = g.heads + (size_t)run * g.run_stride + c;
+        for (int i = tid; i < (int)XRT_RING; i += XRT_TILE) ring[i] = h->ring[i];
+        SeqStream sq;
+        sq.ring = ring; sq.gen = (uint32_t)uni64(h->gen); sq.pos = (uint32_t)uni64(h->next); sq.used = 0;
+        __syncthreads();
+        int64_t count = 0;
+        for (int64_t p0 = 0; p0 < g.pairs_per_chunk; p0 += 192) {
+            const int64_t left = g.pairs_per_chunk - p0;
+            const uint32_t cand = left < 192 ? (uint32_t)left : 192u;
+            __syncthreads();
+            seq_ensure(sq, 4u * cand, tid);
+            bool acc = false;
+            double x1 = 0.0, x2 = 0.0, r2 = 0.0;
+            if ((uint32_t)tid < cand) {
+                x1 = 2.0 * seq_double_at(sq, 2u * (uint32_t)tid) - 1.0;
+                x2 = 2.0 * seq_double_at(sq, 2u * (uint32_t)tid + 1u) - 1.0;
+                r2 = x1 * x1 + x2 * x2;
+                acc = !(r2 >= 1.0 || r2 == 0.0);
+            }
+            uint32_t total;
+            const uint32_t rank = wg_rank(acc, wave_tot, slot, tid, total);
+            if (g.mode == 2 && acc) {
+                const int64_t p = (int64_t)prefix + count + (int64_t)rank;
+                if (p < need_pairs) {
+                    const double f = sqrt(-2.0 * log(r2) / r2);
+                    double* w = g.wl + (size_t)run * (size_t)g.n_values;
+                    w[2 * p] = g.loc + g.sigma * (f * x2);
+                    w[2 * p + 1] = g.loc + g.sigma * (f * x1);
+                    if (p == need_pairs - 1)
+                        g.end_words[run] = 4ull * ((uint64_t)c * (uint64_t)g.pairs_per_chunk + (uint64_t)p0 + (uint64_t)tid + 1ull);
+                }
+            }
+            seq_advance(sq, 4u * cand);
+            count += total;
+            if (g.mode == 2 && (int64_t)prefix + count >= need_pairs) break;
+        }
+        __syncthreads();
+        if (g.mode == 1 && tid == 0) g.acc[unit] = (uint32_t)count;
+        if (g.mode == 2 && tid == 0 && c + 1u == (uint32_t)g.n_chunks && (int64_t)prefix + count < need_pairs) atomicOr(g.flags, 4u);
+        __syncthreads();
+    }
+}
 
 // ==========================================================================
 // host side of the C ABI
@@ -1881,12 +1991,20 @@ static size_t ws_off_polys(const xrt_scene_t* sc, int n_runs)
 
 // The staged path (xrt_staged.inc) is needed when the stream is consumed in a data-dependent
 // way before the Bragg uniforms, or by more than one Bragg optic.
+// np.random.normal wavelengths can be prepared as an array for the fused path (xrt_gauss_kernel) when the
+// ray count is even (no cached second value is left over) and large enough for the jump-ahead
+static bool gauss_prepared(const xrt_source_t& s)
+{
+    return s.wavelength_dist == XRT_WL_NORMAL && (s.intensity % 2) == 0 && s.intensity >= 2 * XRT_TILE &&
+           !getenv("XICSRT_NO_JUMP") && !getenv("XICSRT_STAGED_GAUSS");
+}
+
 static bool needs_staged(const xrt_scene_t* sc)
 {
     const xrt_source_t& s = sc->source;
     if (s.kind == XRT_SRC_PLASMA || s.kind == XRT_SRC_EXTERNAL) return true;
-    if (s.spatial_dist == XRT_SPATIAL_GAUSSIAN || s.angular_dist == XRT_ANG_ISOTROPIC_XY || s.wavelength_dist == XRT_WL_NORMAL)
-        return true;
+    if (s.spatial_dist == XRT_SPATIAL_GAUSSIAN || s.angular_dist == XRT_ANG_ISOTROPIC_XY) return true;
+    if (s.wavelength_dist == XRT_WL_NORMAL && !gauss_prepared(s)) return true;
     int n_bragg = 0;
     for (int e = 0; e < sc->n_optics; e++) {
         if (sc->optics[e].interact == XRT_INTERACT_MOSAIC) return true;     // whole-array passes per layer
@@ -1948,18 +2066,24 @@ static int staged_slots(const xrt_scene_t* sc, int n_runs)
 }
 static size_t staged_bytes(const xrt_scene_t* sc, int n_runs)
 {
-    if (!needs_staged(sc)) return 0;
+    // (a scene with Gaussian wavelengths can be sent to the staged path at run time: a cached gauss value)
+    if (!needs_staged(sc) && sc->source.wavelength_dist != XRT_WL_NORMAL) return 0;
     return al256((size_t)staged_slots(sc, n_runs) * staged_slot_bytes(sc) + 256);
 }
 
 // Few runs of many rays: split every run into segments so that the whole chip has work
 // (the unit of parallelism is otherwise one workgroup per run).  seg_len is a multiple of the tile.
-struct SegPlan { int n_seg; int64_t seg_len; };
+struct SegPlan {
+    int n_seg; int64_t seg_len;     // n_seg == 1 && seg_len == 0: one unit per run, unsegmented kernels
+    int n_chunk_heads;              // stream heads behind the source arrays, 2 * seg_len words apart
+    int n_gchunks; int64_t gpairs;  // Gaussian wavelengths: chunks of the candidate stream, candidate pairs per chunk
+};
 static SegPlan plan_segments(const xrt_scene_t* sc, int n_runs)
 {
-    SegPlan p = {1, 0};
+    SegPlan p = {1, 0, 0, 0, 0};
     if (needs_staged(sc)) return p;
     const int64_t N = sc->source.intensity;
+    const bool gauss = gauss_prepared(sc->source);
     int want = 0;
     int64_t min_len = 4096;                     // below this the jump-ahead of a unit's heads outweighs its rays
     if (const char* e = getenv("XICSRT_SEGMENTS")) { want = atoi(e); min_len = XRT_TILE; }
@@ -1968,24 +2092,51 @@ static SegPlan plan_segments(const xrt_scene_t* sc, int n_runs)
         if (const char* t = getenv("XICSRT_TARGET_UNITS")) target = atoi(t) > 0 ? atoi(t) : target;
         want = (target + n_runs - 1) / n_runs;
     }
-    if (want <= 1 || N < 2 * XRT_TILE || getenv("XICSRT_NO_JUMP")) return p;
-    int64_t len = (N + want - 1) / want;
-    if (len < min_len) len = min_len;
-    len = (len + XRT_TILE - 1) / XRT_TILE * XRT_TILE;
-    const int64_t n = (N + len - 1) / len;
-    if (n <= 1 || n > 4096) return p;
+    int64_t n = 1, len = 0;
+    if (!(want <= 1 || N < 2 * XRT_TILE || getenv("XICSRT_NO_JUMP"))) {
+        len = (N + want - 1) / want;
+        if (len < min_len) len = min_len;
+        len = (len + XRT_TILE - 1) / XRT_TILE * XRT_TILE;
+        n = (N + len - 1) / len;
+        if (n <= 1 || n > 4096) { n = 1; len = 0; }
+    }
+    if (n == 1 && !gauss) return p;
+    if (n == 1) len = (N + XRT_TILE - 1) / XRT_TILE * XRT_TILE;       // whole runs through the SEG kernels
     p.n_seg = (int)n; p.seg_len = len;
+    uint64_t gauss_words = 0;
+    if (gauss) {
+        // candidate pairs that certainly yield N/2 accepted ones (acceptance pi/4; mean + ~8 sigma + slack)
+        const double need = (double)(N / 2);
+        const int64_t cand = (int64_t)(need / 0.7853981633974483 + 8.0 * sqrt(need) + 1024.0);
+        int chunks = (512 + n_runs - 1) / n_runs;
+        const int64_t most = (cand + 1023) / 1024;                       // at least 1024 pairs per chunk
+        if (chunks > most) chunks = (int)most;
+        if (chunks < 1) chunks = 1;
+        int64_t per = (cand + chunks - 1) / chunks;
+        per = (per + 63) / 64 * 64;
+        p.gpairs = per;
+        p.n_gchunks = (int)((cand + per - 1) / per);
+        gauss_words = 4ull * (uint64_t)p.gpairs * (uint64_t)p.n_gchunks;
+    }
+    const uint64_t CH = 2ull * (uint64_t)len;
+    p.n_chunk_heads = (int)((gauss_words + 2ull * (uint64_t)N + CH - 1) / CH) + 1;
     return p;
 }
-// segmented runs: [dst heads n_runs x n_jobs][polys][offsets][unit counts]
-static int seg_jobs(const xrt_scene_t* sc, const SegPlan& p) { return p.n_seg * count_heads(sc) + p.n_seg + 1; }
+static bool seg_active(const SegPlan& p) { return p.n_seg > 1 || p.n_gchunks > 0; }
+// jobs of a run: [segment][source head], the chunk heads, the chunk heads of the Gaussian candidate stream
+static int seg_jobs(const xrt_scene_t* sc, const SegPlan& p) { return p.n_seg * count_heads(sc) + p.n_chunk_heads + p.n_gchunks; }
+// segmented runs: [dst heads n_runs x n_jobs][polys][offsets][unit counts][gauss: values, chunk counts, words]
 static size_t seg_bytes(const xrt_scene_t* sc, int n_runs)
 {
     const SegPlan p = plan_segments(sc, n_runs);
-    if (p.n_seg <= 1) return 0;
+    if (!seg_active(p)) return 0;
     const size_t nj = (size_t)seg_jobs(sc, p);
-    return al256(sizeof(KStream) * nj * (size_t)n_runs) + al256(sizeof(uint32_t) * 624 * nj) + al256(sizeof(uint64_t) * nj)
-           + al256(sizeof(uint32_t) * (size_t)n_runs * (size_t)p.n_seg) + 256;
+    size_t b = al256(sizeof(KStream) * nj * (size_t)n_runs) + al256(sizeof(uint32_t) * 624 * nj) + al256(sizeof(uint64_t) * nj)
+               + al256(sizeof(uint32_t) * (size_t)n_runs * (size_t)p.n_seg) + 256;
+    if (p.n_gchunks > 0)
+        b += al256(sizeof(double) * (size_t)n_runs * (size_t)sc->source.intensity) + al256(sizeof(uint32_t) * (size_t)n_runs * (size_t)p.n_gchunks)
+             + al256(sizeof(uint64_t) * (size_t)n_runs);
+    return b;
 }
 
 extern "C" size_t xrt_workspace_bytes(const xrt_scene_t* sc, int32_t n_runs)
@@ -2011,6 +2162,7 @@ static bool needs_full(const xrt_scene_t* sc)
 {
     const xrt_source_t& s = sc->source;
     if (s.kind == XRT_SRC_FOCUSED || s.angular_dist != XRT_ANG_ISOTROPIC || s.wavelength_dist == XRT_WL_VOIGT) return true;
+    if (s.wavelength_dist == XRT_WL_NORMAL && s.has_velocity) return true;     // Doppler shift of a prepared wavelength
     for (int e = 0; e < sc->n_optics; e++) {
         const xrt_optic_t& o = sc->optics[e];
         if (o.shape == XRT_SHAPE_CYLINDER || o.shape == XRT_SHAPE_TORUS) return true;
@@ -2287,14 +2439,14 @@ static int launch_variant(const KScene& ks, const KArgs& a, int n_runs, size_t l
 // `ahead`: words every stream head has generated beyond `next` when this is called (XRT_AHEAD: the
 // canonical form between kernels; 624: an imported state after xrt_advance_kernel; 0: unknown)
 static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArgs a, int n_runs, bool hist,
-                         int ahead, hipStream_t stream)
+                         int ahead, hipStream_t stream, bool force_staged = false)
 {
     const bool canonical = ahead == (int)XRT_AHEAD;
     const int nh = count_heads(sc);
     KStream* streams = reinterpret_cast<KStream*>(ws + ws_off_streams(sc, n_runs));
     KStream* heads = reinterpret_cast<KStream*>(ws + ws_off_heads(sc, n_runs));
     const int64_t N = ks.src.n_rays;
-    if (needs_staged(sc)) {
+    if (needs_staged(sc) || force_staged) {
         // general path: array-at-a-time passes with one sequential stream head per run
         KStaged g;
         memset(&g, 0, sizeof(g));
@@ -2360,8 +2512,8 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
         if (ti >= 0) HIP_TRY(hipEventRecord(timing_ev[ti][1], stream));
         return 0;
     }
-    const SegPlan plan = ahead > 0 ? plan_segments(sc, n_runs) : SegPlan{1, 0};
-    if (plan.n_seg > 1) {
+    const SegPlan plan = ahead > 0 ? plan_segments(sc, n_runs) : SegPlan{1, 0, 0, 0, 0};
+    if (seg_active(plan)) {
         // ---- segmented runs -------------------------------------------------------------------------
         const int S = plan.n_seg, nj = seg_jobs(sc, plan);
         const int64_t L = plan.seg_len, CH = 2 * L;
@@ -2373,9 +2525,13 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
         uint32_t* d_polys = reinterpret_cast<uint32_t*>(base + al256(sizeof(KStream) * (size_t)nj * (size_t)n_runs));
         uint64_t* d_off = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(d_polys) + al256(sizeof(uint32_t) * 624 * (size_t)nj));
         uint32_t* d_cnt = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(d_off) + al256(sizeof(uint64_t) * (size_t)nj));
-        // jobs of a run: [segment][source head], then the chunk heads, then the stream head behind the arrays
+        double* d_wl = reinterpret_cast<double*>(reinterpret_cast<char*>(d_cnt) + al256(sizeof(uint32_t) * (size_t)n_runs * (size_t)S) + 256);
+        uint32_t* d_gacc = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(d_wl) + al256(sizeof(double) * (size_t)n_runs * (size_t)N));
+        uint64_t* d_gend = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(d_gacc) + al256(sizeof(uint32_t) * (size_t)n_runs * (size_t)(plan.n_gchunks > 0 ? plan.n_gchunks : 1)));
+        const int n_ch = plan.n_chunk_heads, n_gch = plan.n_gchunks;
+        const uint64_t GCH = 4ull * (uint64_t)plan.gpairs;
         // polynomials + offsets of a plan live in pinned host memory and are reused by later calls
-        struct PlanCache { int64_t N, L; int S, nj; uint32_t used; int n_arrays, ahead; uint32_t* polys; uint64_t* offs; };
+        struct PlanCache { int64_t N, L, gpairs; int S, nj, n_ch; uint32_t used; int n_arrays, ahead; uint32_t* polys; uint64_t* offs; };
         static std::mutex plan_mu;
         static std::vector<PlanCache> plans;
         PlanCache hit;
@@ -2384,7 +2540,7 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
             std::lock_guard<std::mutex> lock(plan_mu);
             for (const PlanCache& c : plans)
                 if (c.N == N && c.L == L && c.S == S && c.nj == nj && c.used == ks.src.array_used && c.n_arrays == ks.src.n_arrays &&
-                    c.ahead == ahead) hit = c;
+                    c.ahead == ahead && c.n_ch == n_ch && c.gpairs == plan.gpairs) hit = c;
         }
         if (hit.polys) {
             HIP_TRY(hipMemcpyAsync(d_polys, hit.polys, sizeof(uint32_t) * 624 * (size_t)nj, hipMemcpyHostToDevice, stream));
@@ -2398,8 +2554,8 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
             for (int k = 0; k < ks.src.n_arrays; k++)
                 if ((ks.src.array_used >> k) & 1u) offs[j++] = 2ull * ((uint64_t)k * (uint64_t)N + (uint64_t)sgm * (uint64_t)L);
         const uint64_t behind = 2ull * (uint64_t)ks.src.n_arrays * (uint64_t)N;
-        for (int c = 0; c < S; c++) offs[j++] = behind + (uint64_t)c * (uint64_t)CH;
-        offs[j++] = behind;
+        for (int c = 0; c < n_ch; c++) offs[j++] = behind + (uint64_t)c * (uint64_t)CH;
+        for (int c = 0; c < n_gch; c++) offs[j++] = behind + (uint64_t)c * GCH;
         if (j != nj) return fail(-5, "%s", "segment job count mismatch");
         polys.assign((size_t)nj * 624, 0);
         {
@@ -2413,6 +2569,7 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
         }
         PlanCache c;
         c.N = N; c.L = L; c.S = S; c.nj = nj; c.used = ks.src.array_used; c.n_arrays = ks.src.n_arrays; c.ahead = ahead;
+        c.n_ch = n_ch; c.gpairs = plan.gpairs;
         c.polys = nullptr; c.offs = nullptr;
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c.polys), sizeof(uint32_t) * 624 * (size_t)nj, hipHostMallocDefault));
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c.offs), sizeof(uint64_t) * (size_t)nj, hipHostMallocDefault));
@@ -2444,16 +2601,38 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
         a.run_counter = reinterpret_cast<uint32_t*>(ws);
         a.n_seg = S; a.seg_len = L; a.unit_count = d_cnt; a.chunk_heads = dst + (size_t)S * nh; a.chunk_words = CH;
         a.run_stride = nj;
-        const int variant = needs_ext(sc) ? 2 : (needs_full(sc) ? 1 : 0);
+        a.wl_array = nullptr; a.base_words = nullptr;
+        if (n_gch > 0) {
+            // np.random.normal wavelengths of every run as an array (count pass only when a run has several chunks)
+            KGauss gk;
+            memset(&gk, 0, sizeof(gk));
+            gk.heads = dst + (size_t)S * nh + n_ch; gk.run_stride = nj; gk.pairs_per_chunk = plan.gpairs; gk.n_values = N;
+            gk.n_chunks = n_gch; gk.n_runs = n_runs; gk.acc = d_gacc; gk.wl = d_wl; gk.end_words = d_gend;
+            gk.loc = sc->source.wavelength; gk.sigma = sc->source.wl_a;
+            gk.counter = reinterpret_cast<uint32_t*>(ws); gk.flags = reinterpret_cast<uint32_t*>(ws) + 16;
+            int gunits = n_runs * n_gch, ggrid = gunits < 1024 ? gunits : 1024;
+            for (int mode = (n_gch > 1 ? 1 : 2); mode <= 2; mode++) {
+                gk.mode = mode;
+                HIP_TRY(hipMemsetAsync(ws, 0, 64, stream));
+                hipLaunchKernelGGL(xrt_gauss_kernel, dim3(ggrid), dim3(XRT_TILE), 0, stream, gk);
+                HIP_TRY(hipGetLastError());
+            }
+            a.wl_array = d_wl; a.base_words = d_gend;
+        }
+        int variant = needs_ext(sc) ? 2 : (needs_full(sc) ? 1 : 0);
+        if (variant == 0 && n_gch > 0) variant = 3;         // lean geometry, wavelength per ray from the prepared array
         const size_t lds = lds_bytes(nh, variant == 2);
-        for (int mode = (be >= 0 ? 1 : 2); mode <= 2; mode++) {
+        // (a run that is one segment has nothing in front of it: no count pass)
+        for (int mode = ((be >= 0 && S > 1) ? 1 : 2); mode <= 2; mode++) {
             a.mode = mode;
             HIP_TRY(hipMemsetAsync(ws, 0, 64, stream));
             int st;
-            if (hist) st = variant == 2 ? launch_variant<true, 2, true>(ks, a, n_runs, lds, stream)
+            if (hist) st = variant == 3 ? launch_variant<true, 3, true>(ks, a, n_runs, lds, stream)
+                         : variant == 2 ? launch_variant<true, 2, true>(ks, a, n_runs, lds, stream)
                          : variant == 1 ? launch_variant<true, 1, true>(ks, a, n_runs, lds, stream)
                                         : launch_variant<true, 0, true>(ks, a, n_runs, lds, stream);
-            else      st = variant == 2 ? launch_variant<false, 2, true>(ks, a, n_runs, lds, stream)
+            else      st = variant == 3 ? launch_variant<false, 3, true>(ks, a, n_runs, lds, stream)
+                         : variant == 2 ? launch_variant<false, 2, true>(ks, a, n_runs, lds, stream)
                          : variant == 1 ? launch_variant<false, 1, true>(ks, a, n_runs, lds, stream)
                                         : launch_variant<false, 0, true>(ks, a, n_runs, lds, stream);
             if (st) return st;
@@ -2581,13 +2760,15 @@ extern "C" int xrt_trace_history(const xrt_scene_t* sc, const xrt_rng_state_t* s
     a.images = reinterpret_cast<unsigned long long*>(images);
     a.hist = rays; a.hmask = mask;
     int ahead = 0;
-    if (plan_segments(sc, 1).n_seg > 1) {
+    // np.random.normal with a cached second value pending: the array cannot be prepared in pairs
+    const bool force_staged = sc->source.wavelength_dist == XRT_WL_NORMAL && state_in->has_gauss != 0;
+    if (seg_active(plan_segments(sc, 1)) && !force_staged) {
         // segmented history run: the imported state gets the fixed lead the jump polynomials are made for
         hipLaunchKernelGGL(xrt_advance_kernel, dim3(1), dim3(64), 0, stream, streams);
         HIP_TRY(hipGetLastError());
         ahead = 624;
     }
-    st = run_iteration(sc, ks, ws, a, 1, true, ahead, stream);
+    st = run_iteration(sc, ks, ws, a, 1, true, ahead, stream, force_staged);
     if (st) return st;
     if (state_out) {
         hipLaunchKernelGGL(xrt_export_state_kernel, dim3(1), dim3(64), 0, stream, streams,
@@ -2636,6 +2817,8 @@ extern "C" int xrt_check(void* workspace, void* stream_)
     HIP_TRY(hipMemcpy(&flags, reinterpret_cast<char*>(workspace) + 64, sizeof(flags), hipMemcpyDeviceToHost));
     if (flags & 2u)
         return fail(-7, "%s", "intensity of less than one encountered. Turn on poisson statistics.");
+    if (flags & 4u)
+        return fail(-8, "%s", "Gaussian wavelength sampler ran out of provisioned candidates (a > 8 sigma event)");
     if (flags & 1u)
         return fail(-6, "%s", "plasma source produced more rays than the declared capacity (Poisson tail): results are truncated");
     return 0;
