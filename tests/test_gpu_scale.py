@@ -220,3 +220,50 @@ def test_segmented_runs_chain_iterations(bragg, monkeypatch):
     n_cpu, i_cpu = helpers.oracle_counts(flat, seeds, 3)
     assert np.array_equal(n_gpu, n_cpu), (n_gpu, n_cpu)
     assert np.array_equal(i_gpu[:flat.image_bins], i_cpu[:flat.image_bins])
+
+
+def _thermal(n_rays, runs, seed, iters=1):
+    cfg = _spectrometer(n_rays, runs, seed=seed, rocking_fwhm=2e-3)
+    cfg['sources']['source'].update(temperature=1500.0, mass_number=39.948, linewidth=0.0)
+    cfg['general']['number_of_iter'] = iters
+    return cfg
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n_rays,segments', [(300000, None), (100000, '5'), (100001, None), (4096, '3')])
+def test_gaussian_wavelengths_prepared_or_staged_equal_oracle(n_rays, segments, monkeypatch):
+    """np.random.normal wavelengths: even ray counts go through the prepared array + fused kernels (chunked
+    candidate stream, several iterations chained), odd ones through the staged path; both equal the oracle."""
+    if segments:
+        monkeypatch.setenv('XICSRT_SEGMENTS', segments)
+    cfg = _thermal(n_rays, 3, seed=31, iters=2)
+    config, elements, flat = helpers.build(cfg)
+    seeds = xrt.run_seeds(31, 3)
+    n_gpu, i_gpu = _trace(flat, seeds, 2)
+    n_cpu, i_cpu = helpers.oracle_counts(flat, seeds, 2, threads=3)
+    assert np.array_equal(n_gpu, n_cpu), (n_gpu, n_cpu)
+    assert np.array_equal(i_gpu[:flat.image_bins], i_cpu[:flat.image_bins])
+
+
+@pytest.mark.gpu
+def test_gaussian_wavelengths_with_a_cached_value_pending():
+    """A generator state with a cached gauss value (has_gauss = 1) cannot be served by the pairwise prepared
+    array: the library falls back to the staged path and still equals the oracle ray for ray."""
+    cfg = _thermal(20000, 1, seed=5)
+    config, elements, flat = helpers.build(cfg)
+    rs = np.random.RandomState(77)
+    rs.standard_normal(3)                                   # leaves one value cached
+    st = rs.get_state()
+    assert st[3] == 1
+    state = helpers.xscene.RngState()
+    import ctypes as C
+    C.memmove(state.key, np.ascontiguousarray(st[1], dtype=np.uint32).ctypes.data, 624 * 4)
+    state.pos, state.has_gauss, state.gauss = int(st[2]), int(st[3]), float(st[4])
+    dev = xrt.DeviceTrace(flat)
+    rays, mask, st_out = dev.trace_history((st[1], st[2], st[3], st[4]))
+    o_num, o_img, o_rays, o_mask, o_st = helpers.oracle_history(flat, state)
+    assert np.array_equal(mask, o_mask)
+    both = ~np.isnan(o_rays)
+    assert np.array_equal(np.isnan(rays), np.isnan(o_rays))
+    assert np.max(np.abs(rays[both] - o_rays[both])) <= 1e-12
+    assert (st_out[1], st_out[2]) == (int(o_st.pos), int(o_st.has_gauss))
