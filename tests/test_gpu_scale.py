@@ -267,3 +267,24 @@ def test_gaussian_wavelengths_with_a_cached_value_pending():
     assert np.array_equal(np.isnan(rays), np.isnan(o_rays))
     assert np.max(np.abs(rays[both] - o_rays[both])) <= 1e-12
     assert (st_out[1], st_out[2]) == (int(o_st.pos), int(o_st.has_gauss))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('env', ['XICSRT_NO_JUMP', 'XICSRT_NO_STAGE_SPLIT', 'XICSRT_STAGED_GAUSS'])
+@pytest.mark.parametrize('name', ['C_sphere_runs_iters', 'W_normal_1e5', 'F_plasma_counts', 'Q_four_counts', 'B_mirror_runs'])
+def test_alternative_device_paths_equal_reference(name, env, monkeypatch):
+    """The library's fallbacks (sequential walk instead of jump-ahead, one-launch staged kernel, staged Gaussian
+    wavelengths) are alternative routes to the same integers."""
+    monkeypatch.setenv(env, '1')
+    cfg, gold = helpers.load_golden(name)
+    config, elements, flat = helpers.build(cfg)
+    g = config['general']
+    seeds = xrt.run_seeds(g['random_seed'], g['number_of_runs'])
+    dev = xrt.DeviceTrace(flat)
+    dev.trace(seeds, g['number_of_iter'], keep_images=True)
+    meta, image = dev.results()
+    for nm in flat.names:
+        assert int(meta[nm]['num_out']) == int(gold['num_out/' + nm]), nm
+    for nm in flat.names[1:]:
+        if image[nm] is not None:
+            assert np.array_equal(image[nm].astype(np.int64), gold['image/' + nm]), nm
