@@ -553,274 +553,7 @@ __device__ __forceinline__ V3 surface_normal(const KOptic& op, const V3& X)
     return nrm;
 }
 
-// ---- mesh optics (optics/_ShapeMesh.py), rays already in the optic's frame -------------------
-
-// Moller-Trumbore over every face, later faces overwrite earlier hits (:289-348).  The two
-// 'i,ji->j' products go through BLAS in the reference (fused order), the others are numpy's own.
-__device__ bool mesh_intersect_1(const double* P0, const double* E1, const double* E2, int nf, const Ray& ray, V3& X, int& face)
-{
-    const double epsilon = 1e-15;
-    bool hit = false;
-    for (int ii = 0; ii < nf; ii++) {
-        const V3 p0 = ld3(P0 + 3 * ii), e1 = ld3(E1 + 3 * ii), e2 = ld3(E2 + 3 * ii);
-        const V3 h = cross3(ray.d, e2);
-        double f = dot_blas(h, e1);
-        if ((f > -epsilon) && (f < epsilon)) continue;
-        f = 1.0 / f;
-        const V3 s = sub3(ray.o, p0);
-        const double u = f * dot_e(s, h);
-        if ((u < 0.0) || (u > 1.0)) continue;
-        const V3 q = cross3(s, e1);
-        const double v = f * dot_e(ray.d, q);
-        if ((v < 0.0) || (u + v > 1.0)) continue;
-        const double t = f * dot_blas(q, e2);
-        hit = true;
-        face = ii;
-        X.x = ray.o.x + t * ray.d.x; X.y = ray.o.y + t * ray.d.y; X.z = ray.o.z + t * ray.d.z;
-    }
-    return hit;
-}
-
-// cKDTree(points).query(x)[1] (:464-475): the nearest fine-mesh point (exact; lowest index on an
-// exact tie).  Ring search over the x-y buckets: after ring r every point outside the (2r+1)^2
-// block is at least `bound` away in x-y, hence in 3D; stop when the best distance beats that.
-__device__ int mesh_nearest(const KMesh& M, const V3& x)
-{
-    int best = 0;
-    double bd = __builtin_inf();
-    if (M.grid_nx <= 0) {
-        for (int i = 0; i < M.n_points; i++) {
-            const double dx = x.x - M.points[3 * i], dy = x.y - M.points[3 * i + 1], dz = x.z - M.points[3 * i + 2];
-            const double d = (dx * dx + dy * dy) + dz * dz;
-            if (d < bd) { bd = d; best = i; }
-        }
-        return best;
-    }
-    const int nx = M.grid_nx, ny = M.grid_ny;
-    double fx = floor((x.x - M.grid_x0) * M.grid_ihx), fy = floor((x.y - M.grid_y0) * M.grid_ihy);
-    if (!(fx >= 0.0)) fx = 0.0;
-    if (!(fy >= 0.0)) fy = 0.0;
-    const int cx = fx > (double)(nx - 1) ? nx - 1 : (int)fx, cy = fy > (double)(ny - 1) ? ny - 1 : (int)fy;
-    best = -1;
-    const int rmax = nx > ny ? nx : ny;
-    for (int r = 0; r <= rmax; r++) {
-        const int xlo = cx - r, xhi = cx + r, ylo = cy - r, yhi = cy + r;
-        const int ya = ylo < 0 ? 0 : ylo, yb = yhi > ny - 1 ? ny - 1 : yhi;
-        for (int yy = ya; yy <= yb; yy++) {
-            const bool whole_row = (yy == ylo) || (yy == yhi);
-            const int step = (whole_row || r == 0) ? 1 : 2 * r;
-            for (int xx = xlo; xx <= xhi; xx += step) {
-                if (xx < 0 || xx >= nx) continue;
-                const int c = yy * nx + xx;
-                const int c0 = M.cell_start[c], c1 = M.cell_start[c + 1];
-                for (int k = c0; k < c1; k++) {
-                    const double dx = x.x - M.cell_xyz[3 * k], dy = x.y - M.cell_xyz[3 * k + 1], dz = x.z - M.cell_xyz[3 * k + 2];
-                    const double d = (dx * dx + dy * dy) + dz * dz;
-                    const int i = M.cell_idx[k];
-                    if (d < bd || (d == bd && i < best)) { bd = d; best = i; }
-                }
-            }
-        }
-        double bound = __builtin_inf();
-        if (xlo > 0)      bound = fmin(bound, x.x - (M.grid_x0 + (double)xlo * M.grid_hx));
-        if (xhi < nx - 1) bound = fmin(bound, (M.grid_x0 + (double)(xhi + 1) * M.grid_hx) - x.x);
-        if (ylo > 0)      bound = fmin(bound, x.y - (M.grid_y0 + (double)ylo * M.grid_hy));
-        if (yhi < ny - 1) bound = fmin(bound, (M.grid_y0 + (double)(yhi + 1) * M.grid_hy) - x.y);
-        if (bound == __builtin_inf()) break;                     // the block covers the whole grid
-        bound -= M.grid_tiny;
-        if (best >= 0 && bound > 0.0 && bd < bound * bound) break;
-    }
-    return best < 0 ? 0 : best;
-}
-
-// the <= 8 faces around the nearest point: plane hit + area-sum test, first passing (:350-426)
-__device__ bool mesh_intersect_2(const KMesh& M, int idx, const Ray& ray, V3& X, int& face)
-{
-    for (int k = 0; k < 8; k++) {
-        const int f = M.p_faces_idx[k * M.n_points + idx];
-        const bool valid = M.p_faces_mask[k * M.n_points + idx] != 0;
-        const V3 p0 = ld3(M.p0 + 3 * f), p1 = ld3(M.p1 + 3 * f), p2 = ld3(M.p2 + 3 * f), n = ld3(M.faces_normal + 3 * f);
-        const V3 t0 = sub3(p0, ray.o);
-        const double t1 = dot_e(t0, n), t2 = dot_e(ray.d, n);
-        const double dist = t1 / t2;
-        V3 I;
-        I.x = ray.d.x * dist + ray.o.x; I.y = ray.d.y * dist + ray.o.y; I.z = ray.d.z * dist + ray.o.z;
-        const V3 a = sub3(I, p0), b = sub3(I, p1), c = sub3(I, p2);
-        const double diff = ((norm3(cross3(b, c)) + norm3(cross3(c, a))) + norm3(cross3(a, b))) - M.faces_area[f];
-        if ((diff < 1e-10) && (dist >= 0) && valid) { X = I; face = f; return true; }
-    }
-    return false;
-}
-
-// SciPy CloughTocher2DInterpolator (third party, scipy 1.15.3): barycentric walk + the cubic
-// Bezier evaluation of _clough_tocher_2d_single with affine-invariant edge directions.
-__device__ __forceinline__ void ct_bary(const double* T, double x0, double x1, double* c)
-{
-    c[2] = 1.0;
-    c[0] = 0.0; c[0] += T[0] * (x0 - T[4]); c[0] += T[1] * (x1 - T[5]); c[2] -= c[0];
-    c[1] = 0.0; c[1] += T[2] * (x0 - T[4]); c[1] += T[3] * (x1 - T[5]); c[2] -= c[1];
-}
-
-__device__ int ct_find_simplex(const KMesh& M, double x0, double x1, int start, double* c)
-{
-    const double eps = 100 * 2.220446049250313e-16;
-    if (x0 != x0 || x1 != x1) return -1;
-    int s = start;
-    for (int iter = 0; iter < M.n_simplices + 8; iter++) {
-        ct_bary(M.ct_transform + 6 * s, x0, x1, c);
-        int worst = -1;
-        double wv = -eps;
-        for (int k = 0; k < 3; k++) if (c[k] < wv) { wv = c[k]; worst = k; }
-        if (worst < 0) return s;
-        const int nb = M.ct_neighbors[3 * s + worst];
-        if (nb < 0) break;
-        s = nb;
-    }
-    for (s = 0; s < M.n_simplices; s++) {
-        ct_bary(M.ct_transform + 6 * s, x0, x1, c);
-        if (c[0] >= -eps && c[1] >= -eps && c[2] >= -eps) return s;
-    }
-    return -1;
-}
-
-// the parts of the evaluation that do not depend on which of the four interpolated quantities is
-// asked for: edge vectors, the neighbour weights g, and the 19 Bernstein products of the point
-struct CtShared {
-    int v0, v1, v2;
-    double e12x, e12y, e23x, e23y, e31x, e31y;
-    double g[3];
-    double m[19];
-};
-
-__device__ void ct_shared(const KMesh& M, int isimplex, const double* b, CtShared& G)
-{
-    const int* v = M.ct_simplices + 3 * isimplex;
-    const double* pts = M.ct_points;
-    G.v0 = v[0]; G.v1 = v[1]; G.v2 = v[2];
-    G.e12x = pts[2 * v[1]] - pts[2 * v[0]]; G.e12y = pts[2 * v[1] + 1] - pts[2 * v[0] + 1];
-    G.e23x = pts[2 * v[2]] - pts[2 * v[1]]; G.e23y = pts[2 * v[2] + 1] - pts[2 * v[1] + 1];
-    G.e31x = pts[2 * v[0]] - pts[2 * v[2]]; G.e31y = pts[2 * v[0] + 1] - pts[2 * v[2] + 1];
-    for (int k = 0; k < 3; k++) {
-        const int itri = M.ct_neighbors[3 * isimplex + k];
-        if (itri == -1) { G.g[k] = -1. / 2; continue; }
-        const int* w = M.ct_simplices + 3 * itri;
-        double c[3];
-        const double y0 = (pts[2 * w[0]] + pts[2 * w[1]] + pts[2 * w[2]]) / 3;
-        const double y1 = (pts[2 * w[0] + 1] + pts[2 * w[1] + 1] + pts[2 * w[2] + 1]) / 3;
-        ct_bary(M.ct_transform + 6 * isimplex, y0, y1, c);
-        if (k == 0)      G.g[k] = (2 * c[2] + c[1] - 1) / (2 - 3 * c[2] - 3 * c[1]);
-        else if (k == 1) G.g[k] = (2 * c[0] + c[2] - 1) / (2 - 3 * c[0] - 3 * c[2]);
-        else             G.g[k] = (2 * c[1] + c[0] - 1) / (2 - 3 * c[1] - 3 * c[0]);
-    }
-    double minval = b[0];
-    for (int k = 0; k < 3; k++) if (b[k] < minval) minval = b[k];
-    const double b1 = b[0] - minval, b2 = b[1] - minval, b3 = b[2] - minval, b4 = 3 * minval;
-    double* m = G.m;
-    m[0] = pow(b1, 3);            m[1] = 3 * pow(b1, 2) * b2;   m[2] = 3 * pow(b1, 2) * b3;  m[3] = 3 * pow(b1, 2) * b4;
-    m[4] = 3 * b1 * pow(b2, 2);   m[5] = 6 * b1 * b2 * b4;      m[6] = 3 * b1 * pow(b3, 2);  m[7] = 6 * b1 * b3 * b4;
-    m[8] = 3 * b1 * pow(b4, 2);   m[9] = pow(b2, 3);            m[10] = 3 * pow(b2, 2) * b3; m[11] = 3 * pow(b2, 2) * b4;
-    m[12] = 3 * b2 * pow(b3, 2);  m[13] = 6 * b2 * b3 * b4;     m[14] = 3 * b2 * pow(b4, 2); m[15] = pow(b3, 3);
-    m[16] = 3 * pow(b3, 2) * b4;  m[17] = 3 * b3 * pow(b4, 2);  m[18] = pow(b4, 3);
-}
-
-__device__ double ct_eval(const KMesh& M, const CtShared& G, int which)
-{
-    const double* val = M.ct_values + (size_t)which * M.n_points;
-    const double* grd = M.ct_grad + (size_t)which * M.n_points * 2;
-    const double f1 = val[G.v0], f2 = val[G.v1], f3 = val[G.v2];
-    const double* d1 = grd + 2 * G.v0; const double* d2 = grd + 2 * G.v1; const double* d3 = grd + 2 * G.v2;
-    const double df12 = +(d1[0] * G.e12x + d1[1] * G.e12y);
-    const double df21 = -(d2[0] * G.e12x + d2[1] * G.e12y);
-    const double df23 = +(d2[0] * G.e23x + d2[1] * G.e23y);
-    const double df32 = -(d3[0] * G.e23x + d3[1] * G.e23y);
-    const double df31 = +(d3[0] * G.e31x + d3[1] * G.e31y);
-    const double df13 = -(d1[0] * G.e31x + d1[1] * G.e31y);
-    const double c3000 = f1, c2100 = (df12 + 3 * c3000) / 3, c2010 = (df13 + 3 * c3000) / 3;
-    const double c0300 = f2, c1200 = (df21 + 3 * c0300) / 3, c0210 = (df23 + 3 * c0300) / 3;
-    const double c0030 = f3, c1020 = (df31 + 3 * c0030) / 3, c0120 = (df32 + 3 * c0030) / 3;
-    const double c2001 = (c2100 + c2010 + c3000) / 3;
-    const double c0201 = (c1200 + c0300 + c0210) / 3;
-    const double c0021 = (c1020 + c0120 + c0030) / 3;
-    const double* g = G.g;
-    const double c0111 = (g[0] * (-c0300 + 3 * c0210 - 3 * c0120 + c0030) + (-c0300 + 2 * c0210 - c0120 + c0021 + c0201)) / 2;
-    const double c1011 = (g[1] * (-c0030 + 3 * c1020 - 3 * c2010 + c3000) + (-c0030 + 2 * c1020 - c2010 + c2001 + c0021)) / 2;
-    const double c1101 = (g[2] * (-c3000 + 3 * c2100 - 3 * c1200 + c0300) + (-c3000 + 2 * c2100 - c1200 + c2001 + c0201)) / 2;
-    const double c1002 = (c1101 + c1011 + c2001) / 3;
-    const double c0102 = (c1101 + c0111 + c0201) / 3;
-    const double c0012 = (c1011 + c0111 + c0021) / 3;
-    const double c0003 = (c1002 + c0102 + c0012) / 3;
-    const double* m = G.m;
-    return (m[0] * c3000 + m[1] * c2100 + m[2] * c2010 + m[3] * c2001 +
-            m[4] * c1200 + m[5] * c1101 + m[6] * c1020 + m[7] * c1011 +
-            m[8] * c1002 + m[9] * c0300 + m[10] * c0210 + m[11] * c0201 +
-            m[12] * c0120 + m[13] * c0111 + m[14] * c0102 + m[15] * c0030 +
-            m[16] * c0021 + m[17] * c0012 + m[18] * c0003);
-}
-
-// ShapeMesh.intersect (:135-170), position part.  `aux` identifies what the normal is taken
-// from afterwards: the hit face (flat) or the Clough-Tocher simplex (interpolated; -1: outside).
-struct MeshHit { double x, y, z; int aux; int hit; };
-
-__device__ __noinline__ MeshHit mesh_hit(const KMesh* Mp, double ox, double oy, double oz, double dx, double dy, double dz)
-{
-    const KMesh& M = *Mp;
-    Ray ray;
-    ray.o.x = ox; ray.o.y = oy; ray.o.z = oz; ray.d.x = dx; ray.d.y = dy; ray.d.z = dz; ray.wl = 0.0;
-    MeshHit h;
-    h.x = h.y = h.z = 0.0; h.aux = 0; h.hit = 0;
-    V3 X;
-    X.x = X.y = X.z = 0.0;
-    int face = 0, idx = -1;
-    if (M.n_coarse_faces > 0) {
-        V3 xc;
-        if (!mesh_intersect_1(M.c_p0, M.c_edge1, M.c_edge2, M.n_coarse_faces, ray, xc, face)) return h;
-        idx = mesh_nearest(M, xc);
-        if (!mesh_intersect_2(M, idx, ray, X, face)) return h;
-    } else {
-        if (!mesh_intersect_1(M.p0, M.edge1, M.edge2, M.n_faces, ray, X, face)) return h;
-    }
-    h.hit = 1;
-    h.aux = face;
-    if (M.interpolate) {
-        double c[3];
-        int start = (idx >= 0) ? M.ct_vertex_simplex[idx] : 0;
-        if (start < 0) start = 0;
-        const int sx = ct_find_simplex(M, X.x, X.y, start, c);
-        h.aux = sx;
-        if (sx < 0) X.z = __builtin_nan("");
-        else {
-            CtShared G;
-            ct_shared(M, sx, c, G);
-            X.z = ct_eval(M, G, 0);
-        }
-    }
-    h.x = X.x; h.y = X.y; h.z = X.z;
-    return h;
-}
-
-// ShapeMesh.intersect, normal part: the hit face's normal (:428-432), or the interpolated normal
-// re-normalised as (1/|n|) n (:182-193); the barycentric coordinates are those of the walk's last step
-__device__ __noinline__ V3 mesh_normal(const KMesh* Mp, double x, double y, int aux)
-{
-    const KMesh& M = *Mp;
-    V3 nrm;
-    if (M.interpolate) {
-        V3 nn;
-        if (aux < 0) { nn.x = nn.y = nn.z = __builtin_nan(""); }
-        else {
-            double c[3];
-            ct_bary(M.ct_transform + 6 * aux, x, y, c);
-            CtShared G;
-            ct_shared(M, aux, c, G);
-            nn.x = ct_eval(M, G, 1); nn.y = ct_eval(M, G, 2); nn.z = ct_eval(M, G, 3);
-        }
-        const double inv = 1.0 / norm3(nn);
-        nrm.x = inv * nn.x; nrm.y = inv * nn.y; nrm.z = inv * nn.z;
-    } else {
-        nrm = ld3(M.faces_normal + 3 * aux);
-    }
-    return nrm;
-}
+#include "xrt_mesh.inc"
 
 // tools/xicsrt_aperture.py:108-204
 __device__ bool aperture_shape(const xrt_aperture_t& a, double x, double y)
@@ -1092,193 +825,7 @@ void xrt_seek_kernel(KStream* streams, KStream* heads, int n_runs, int n_arrays,
 // first word (J_k = 2kN - 512 from the canonical stream form gen = next + 512).
 // Cost is independent of N; the sequential xrt_seek_kernel remains the general path.
 #define XRT_JUMP_THREADS 1024
-// The 19937+623-word stretch behind a stream head's last 624 state words, built by ONE wave
-// (LDS operations of a wave execute in order, so no workgroup barrier is needed between the
-// dependent steps: <= 227 words are independent, 192 = 3 per lane are produced per step).
-__device__ __forceinline__ void build_stretch(uint32_t* S, int tid)
-{
-    if (tid < 64) {
-        for (int base = 624; base < XRT_STRETCH; base += 192) {
-            const int n0 = base + tid, n1 = n0 + 64, n2 = n0 + 128;
-            const bool v0 = n0 < XRT_STRETCH, v1 = n1 < XRT_STRETCH, v2 = n2 < XRT_STRETCH;
-            uint32_t r0 = 0, r1 = 0, r2 = 0;
-            if (v0) r0 = mt_mix(S[n0 - 624], S[n0 - 623], S[n0 - 227]);
-            if (v1) r1 = mt_mix(S[n1 - 624], S[n1 - 623], S[n1 - 227]);
-            if (v2) r2 = mt_mix(S[n2 - 624], S[n2 - 623], S[n2 - 227]);
-            if (v0) S[n0] = r0;
-            if (v1) S[n1] = r1;
-            if (v2) S[n2] = r2;
-            wave_fence();
-        }
-    }
-    __syncthreads();
-}
-
-// One jump: O[w] = XOR over the set bits j of g (624 mask words) of S[w + j], w < 624.
-// Thread (block b < 156, part p < 5; a part is three whole waves, so the mask word is wave-uniform)
-// accumulates the four outputs 4b..4b+3 over the mask words [125 p, 125 p + 125): per four bits it needs one aligned 128-bit LDS read (the window of
-// S[4b + j .. 4b + j + 6] slides by a quad) and sixteen masked XORs -- no scalar bit scanning, no
-// data-dependent branches; the five partial results meet in O through LDS atomics.
-// S must be readable up to index XRT_STRETCH + 36 (only ever multiplied by zero mask bits there).  O must be zero on entry; ends with a barrier.
-#define XRT_JUMP_PARTS 5
-// acc ^ (x & mask) in one gfx950 instruction (v_bitop3_b32, truth table 0x6A with a = 0xF0, b = 0xCC, c = 0xAA)
-__device__ __forceinline__ uint32_t mxor(uint32_t acc, uint32_t x, uint32_t mask) {
-#ifndef XRT_JUMP_NO_BITOP3
-    return __builtin_amdgcn_bitop3_b32(x, mask, acc, 0x6A);
-#else
-    return acc ^ (x & mask);
-#endif
-}
-
-__device__ __forceinline__ void jump_xor(const uint32_t* S, const uint32_t* g, uint32_t* O, int tid)
-{
-    const int p = tid / 192, b = tid - p * 192;
-    if (p < XRT_JUMP_PARTS && b < 156) {
-        const uint4* Sq = reinterpret_cast<const uint4*>(S + 4 * b);    // quad n = S[4b + 4n .. 4b + 4n + 3]
-        uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-        const int w0 = 125 * p, w1 = (w0 + 125 < 624) ? w0 + 125 : 624;
-        uint4 cur = Sq[8 * w0], nxt = Sq[8 * w0 + 1];
-        for (int mw = w0; mw < w1; mw++) {
-            const uint32_t m = uni32(g[mw]);
-#pragma unroll
-            for (int t = 0; t < 8; t++) {
-                const uint4 far = Sq[8 * mw + t + 2];
-                const uint32_t x0 = cur.x, x1 = cur.y, x2 = cur.z, x3 = cur.w, x4 = nxt.x, x5 = nxt.y, x6 = nxt.z;
-                const uint32_t k0 = 0u - ((m >> (4 * t + 0)) & 1u), k1 = 0u - ((m >> (4 * t + 1)) & 1u);
-                const uint32_t k2 = 0u - ((m >> (4 * t + 2)) & 1u), k3 = 0u - ((m >> (4 * t + 3)) & 1u);
-                a0 = mxor(a0, x0, k0); a1 = mxor(a1, x1, k0); a2 = mxor(a2, x2, k0); a3 = mxor(a3, x3, k0);
-                a0 = mxor(a0, x1, k1); a1 = mxor(a1, x2, k1); a2 = mxor(a2, x3, k1); a3 = mxor(a3, x4, k1);
-                a0 = mxor(a0, x2, k2); a1 = mxor(a1, x3, k2); a2 = mxor(a2, x4, k2); a3 = mxor(a3, x5, k2);
-                a0 = mxor(a0, x3, k3); a1 = mxor(a1, x4, k3); a2 = mxor(a2, x5, k3); a3 = mxor(a3, x6, k3);
-                cur = nxt; nxt = far;
-            }
-        }
-        atomicXor(&O[4 * b + 0], a0); atomicXor(&O[4 * b + 1], a1);
-        atomicXor(&O[4 * b + 2], a2); atomicXor(&O[4 * b + 3], a3);
-    }
-    __syncthreads();
-}
-
-__global__ __launch_bounds__(XRT_JUMP_THREADS)
-void xrt_jump_kernel(KStream* streams, KStream* heads, const uint32_t* polys, int n_runs, int n_arrays,
-                     uint32_t array_used, int n_src_heads, int n_polys, int64_t n_rays)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t jlds[];
-    uint32_t* S = jlds;                         // [XRT_STRETCH + 48]
-    uint32_t* O = jlds + XRT_STRETCH + 48;      // [624] one jump's result
-    uint32_t* P = O + 624;                      // [n_polys][624]
-    const int tid = threadIdx.x;
-    for (int i = tid; i < n_polys * 624; i += XRT_JUMP_THREADS) P[i] = polys[i];
-    if (tid < 48) S[XRT_STRETCH + tid] = 0u;
-    for (int run = blockIdx.x; run < n_runs; run += gridDim.x) {
-        KStream* st = streams + run;
-        const uint64_t gen = uni64(st->gen), next = uni64(st->next);
-        __syncthreads();
-        if (tid < 624) S[tid] = st->ring[((uint32_t)gen - 624u + (uint32_t)tid) & XRT_RMASK];
-        __syncthreads();
-        build_stretch(S, tid);
-        int h = 0, pi = 0;
-        for (int k = 0; k <= n_arrays; k++) {
-            const bool is_stream = (k == n_arrays);
-            if (!is_stream && !((array_used >> k) & 1u)) continue;
-            KStream* out = is_stream ? st : (heads + (size_t)run * n_src_heads + h);
-            const uint64_t target = next + 2ull * (uint64_t)k * (uint64_t)n_rays;
-            if (k == 0) {
-                // the array starts at the stream's own position: plain copy
-                if (tid < (int)XRT_RING) out->ring[tid] = st->ring[tid];
-                if (tid == 0) { out->gen = gen; out->next = next; }
-            } else {
-                const uint32_t* g = P + pi * 624;
-                pi++;
-                __syncthreads();
-                if (tid < 624) O[tid] = 0u;
-                __syncthreads();
-                jump_xor(S, g, O, tid);
-                // window [target-624, target): only these 624 slots of the ring are meaningful
-                if (tid < 624) out->ring[((uint32_t)target - 624u + (uint32_t)tid) & XRT_RMASK] = O[tid];
-                if (tid == 0) { out->gen = target; out->next = target; }
-            }
-            if (!is_stream) h++;
-        }
-    }
-}
-
-// stream -> numpy state.  numpy keeps key = the 624-word block that contains the
-// next word and pos = the offset in it; when that block is still inside the ring it is
-// reproduced exactly.  Otherwise (the head ran more than 400 words ahead) an
-// equivalent state is written: key = the last 624 words generated, pos = 624 - words
-// ahead; the recurrence is translation invariant, so both continue the same stream.
-__global__ __launch_bounds__(64)
-void xrt_export_state_kernel(const KStream* in, const KState* orig, KState* out)
-{
-    __shared__ uint32_t ring[XRT_RING];
-    const int lane = threadIdx.x;
-    for (int i = lane; i < (int)XRT_RING; i += 64) ring[i] = in->ring[i];
-    uint64_t gen = uni64(in->gen);
-    const uint64_t next = uni64(in->next);
-    wave_fence();
-    uint64_t block = (next == 0) ? 0 : ((next - 1) / 624ull) * 624ull;
-    if (gen > block + 1024ull) {
-        block = gen - 624ull;
-    } else {
-        wave_walk(ring, gen, block + 624ull, lane);
-    }
-    for (int i = lane; i < 624; i += 64) out->key[i] = ring[((uint32_t)block + (uint32_t)i) & XRT_RMASK];
-    if (lane == 0) {
-        out->pos = (int32_t)(next - block);
-        out->has_gauss = orig->has_gauss;
-        out->gauss = orig->gauss;
-    }
-}
-
-// Jump-ahead for segmented runs: every run needs n_jobs positioned copies of its stream head
-// (source heads of every segment, the chunk heads of the Bragg stream, the stream head moved
-// behind the source arrays).  job j of a run: polynomial j (t^J mod phi, J = offset - 512 from the
-// canonical form) applied to the run's 19937+623-word stretch -> dst[run * n_jobs + j] at absolute
-// position next + offset; offset[j] < 512 (J <= 0): the head is the stream head itself.  The
-// workgroups of a run (gridDim.y of them) each rebuild the stretch and take every gridDim.y-th job.
-struct KJumpJobs {
-    const uint32_t* polys;      // [n_jobs][624] global
-    const uint64_t* offsets;    // [n_jobs] words from the stream head's `next`
-    KStream* dst;               // [n_runs][n_jobs]
-    int32_t n_jobs, n_runs;
-    uint64_t ahead;             // words the stream heads have generated ahead of `next` (512, or 624 for imported states)
-};
-
-__global__ __launch_bounds__(XRT_JUMP_THREADS)
-void xrt_jump_jobs_kernel(const KStream* streams, const KJumpJobs jobs)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t jlds[];
-    uint32_t* S = jlds;                         // [XRT_STRETCH + 48]
-    uint32_t* O = jlds + XRT_STRETCH + 48;      // [624]
-    const int tid = threadIdx.x;
-    if (tid < 48) S[XRT_STRETCH + tid] = 0u;
-    for (int run = blockIdx.x; run < jobs.n_runs; run += gridDim.x) {
-        const KStream* st = streams + run;
-        const uint64_t gen = uni64(st->gen), next = uni64(st->next);
-        __syncthreads();
-        if (tid < 624) S[tid] = st->ring[((uint32_t)gen - 624u + (uint32_t)tid) & XRT_RMASK];
-        __syncthreads();
-        build_stretch(S, tid);
-        for (int j = blockIdx.y; j < jobs.n_jobs; j += gridDim.y) {
-            KStream* out = jobs.dst + (size_t)run * jobs.n_jobs + j;
-            const uint64_t off = jobs.offsets[j];
-            const uint64_t target = next + off;
-            if (off < jobs.ahead) {
-                if (tid < (int)XRT_RING) out->ring[tid] = st->ring[tid];
-                if (tid == 0) { out->gen = gen; out->next = target; }
-                continue;
-            }
-            const uint32_t* g = jobs.polys + (size_t)j * 624;
-            __syncthreads();
-            if (tid < 624) O[tid] = 0u;
-            __syncthreads();
-            jump_xor(S, g, O, tid);
-            if (tid < 624) out->ring[((uint32_t)target - 624u + (uint32_t)tid) & XRT_RMASK] = O[tid];
-            if (tid == 0) { out->gen = target; out->next = target; }
-        }
-    }
-}
+#include "xrt_jump.inc"
 
 // --------------------------------------------------------------------------
 // the propagation kernel
@@ -1765,102 +1312,7 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
 #include "xrt_staged.inc"
 
 
-// --------------------------------------------------------------------------
-// Gaussian wavelengths for the fused path: np.random.normal(loc, sigma, N) of every run, prepared
-// as an array.  numpy's legacy gauss is the polar method: candidate pairs (two doubles each) are
-// rejected unless 0 < r2 < 1, an accepted pair yields two values (f*x2 first, the cached f*x1 next),
-// so the stream consumption is data dependent.  The candidate stream of a run (it starts right
-// behind the source's uniform arrays) is cut into chunks with jump-positioned heads; mode 1 counts
-// the accepted pairs of every chunk, mode 2 writes the values of its chunk at the indices the counts
-// of the earlier chunks give, and the chunk that holds the last needed pair records how many words
-// the draws consumed (the Bragg uniforms follow there).  N is even and no value is cached on entry
-// (the host falls back to the staged path otherwise).
-// --------------------------------------------------------------------------
-struct KGauss {
-    const KStream* heads;       // chunk g of run r: heads[r * run_stride + g]
-    int64_t  run_stride;
-    int64_t  pairs_per_chunk;   // candidate pairs per chunk (a chunk is 4x as many words)
-    int64_t  n_values;          // N
-    int32_t  n_chunks, n_runs, mode, pad;
-    uint32_t* acc;              // [n_runs][n_chunks] accepted pairs per chunk
-    double*  wl;                // [n_runs][N]
-    uint64_t* end_words;        // [n_runs]
-    double   loc, sigma;
-    uint32_t* counter;
-    uint32_t* flags;            // bit 2: the provisioned candidates did not yield N values
-};
-
-__global__ __launch_bounds__(XRT_TILE)
-void xrt_gauss_kernel(const KGauss g)
-{
-    __shared__ uint32_t ring[XRT_RING];
-    __shared__ uint32_t wave_tot[16];
-    __shared__ unsigned long long sum64;
-    __shared__ uint32_t bcast;
-    const int tid = threadIdx.x;
-    int slot = 0;
-    const int64_t need_pairs = g.n_values / 2;
-    for (;;) {
-        if (tid == 0) bcast = atomicAdd(g.counter, 1u);
-        __syncthreads();
-        const uint32_t unit = uni32(bcast);
-        if (unit >= (uint32_t)g.n_runs * (uint32_t)g.n_chunks) break;
-        const uint32_t run = unit / (uint32_t)g.n_chunks, c = unit - run * (uint32_t)g.n_chunks;
-        // accepted pairs in the earlier chunks of this run
-        unsigned long long prefix = 0;
-        if (g.mode == 2 && g.n_chunks > 1) {
-            if (tid == 0) sum64 = 0ULL;
-            __syncthreads();
-            unsigned long long part = 0;
-            for (uint32_t q = (uint32_t)tid; q < c; q += XRT_TILE) part += g.acc[(size_t)run * g.n_chunks + q];
-            if (part) atomicAdd(&sum64, part);
-            __syncthreads();
-            prefix = uni64(sum64);
-        }
-        __syncthreads();
-        if (g.mode == 2 && (int64_t)prefix >= need_pairs) continue;        // every value lies in earlier chunks
-        const KStream* h = g.heads + (size_t)run * g.run_stride + c;
-        for (int i = tid; i < (int)XRT_RING; i += XRT_TILE) ring[i] = h->ring[i];
-        SeqStream sq;
-        sq.ring = ring; sq.gen = (uint32_t)uni64(h->gen); sq.pos = (uint32_t)uni64(h->next); sq.used = 0;
-        __syncthreads();
-        int64_t count = 0;
-        for (int64_t p0 = 0; p0 < g.pairs_per_chunk; p0 += 192) {
-            const int64_t left = g.pairs_per_chunk - p0;
-            const uint32_t cand = left < 192 ? (uint32_t)left : 192u;
-            __syncthreads();
-            seq_ensure(sq, 4u * cand, tid);
-            bool acc = false;
-            double x1 = 0.0, x2 = 0.0, r2 = 0.0;
-            if ((uint32_t)tid < cand) {
-                x1 = 2.0 * seq_double_at(sq, 2u * (uint32_t)tid) - 1.0;
-                x2 = 2.0 * seq_double_at(sq, 2u * (uint32_t)tid + 1u) - 1.0;
-                r2 = x1 * x1 + x2 * x2;
-                acc = !(r2 >= 1.0 || r2 == 0.0);
-            }
-            uint32_t total;
-            const uint32_t rank = wg_rank(acc, wave_tot, slot, tid, total);
-            if (g.mode == 2 && acc) {
-                const int64_t p = (int64_t)prefix + count + (int64_t)rank;
-                if (p < need_pairs) {
-                    const double f = sqrt(-2.0 * log(r2) / r2);
-                    double* w = g.wl + (size_t)run * (size_t)g.n_values;
-                    w[2 * p] = g.loc + g.sigma * (f * x2);
-                    w[2 * p + 1] = g.loc + g.sigma * (f * x1);
-                    if (p == need_pairs - 1)
-                        g.end_words[run] = 4ull * ((uint64_t)c * (uint64_t)g.pairs_per_chunk + (uint64_t)p0 + (uint64_t)tid + 1ull);
-                }
-            }
-            seq_advance(sq, 4u * cand);
-            count += total;
-            if (g.mode == 2 && (int64_t)prefix + count >= need_pairs) break;
-        }
-        __syncthreads();
-        if (g.mode == 1 && tid == 0) g.acc[unit] = (uint32_t)count;
-        if (g.mode == 2 && tid == 0 && c + 1u == (uint32_t)g.n_chunks && (int64_t)prefix + count < need_pairs) atomicOr(g.flags, 4u);
-        __syncthreads();
-    }
-}
+#include "xrt_gauss.inc"
 
 // ==========================================================================
 // host side of the C ABI
