@@ -251,3 +251,33 @@ def test_import_xicsrt_compatibility_layout(tmp_path):
     finally:
         for k in [k for k in sys.modules if k == 'xicsrt' or k.startswith('xicsrt.')]:
             del sys.modules[k]
+
+
+def test_jump_polynomials_satisfy_the_generator_recurrence():
+    """g = t^J mod phi from the library (host-side GF(2) arithmetic, no GPU): the MT19937 state sequence obeys
+    s[n + J] = XOR over the set bits j of g of s[n + j]; checked for small J, J = 19937 (first reduction) and beyond."""
+    L = capi.lib()
+    buf = (C.c_uint32 * 624)()
+
+    def sequence(count):
+        s = [0] * (624 + count)
+        x = 19650218
+        for i in range(624):
+            s[i] = x
+            x = (1812433253 * (x ^ (x >> 30)) + i + 1) & 0xffffffff
+        for n in range(624, 624 + count):
+            y = (s[n - 624] & 0x80000000) | (s[n - 623] & 0x7fffffff)
+            s[n] = s[n - 227] ^ (y >> 1) ^ (0x9908b0df if y & 1 else 0)
+        return s
+
+    s = sequence(19937 + 66000)
+    for J in (1, 623, 19936, 19937, 19938, 40001, 65537):
+        assert L.xrt_mt_jump_poly(J, buf) == 0
+        g = np.frombuffer(buf, dtype=np.uint32)
+        bits = [j for j in range(19937) if (int(g[j >> 5]) >> (j & 31)) & 1]
+        assert len(bits) >= 1
+        for n in (1, 300, 623):
+            acc = 0
+            for j in bits:
+                acc ^= s[n + j]
+            assert acc == s[n + J], (J, n)
