@@ -1942,7 +1942,7 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
                 const int nb = (n_runs - base_run) < slots ? (n_runs - base_run) : slots;
                 g.run_base = base_run;
                 a.n_runs = nb;
-                int grid1 = nb < 768 ? nb : 768, grid2 = nb < 256 ? nb : 256;       // three source workgroups, one optics workgroup per CU
+                int grid1 = nb < 768 ? nb : 768, grid2 = nb < (special ? 256 : 512) ? nb : (special ? 256 : 512);   // three source, two (one) optics workgroups per CU
                 HIP_TRY(hipMemsetAsync(ws, 0, 64, stream));
                 hipLaunchKernelGGL(k1, dim3(grid1), dim3(XRT_TILE), lds, stream, ks, a, g);
                 HIP_TRY(hipGetLastError());
