@@ -1942,7 +1942,7 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
                 const int nb = (n_runs - base_run) < slots ? (n_runs - base_run) : slots;
                 g.run_base = base_run;
                 a.n_runs = nb;
-                const int g1 = src == 1 ? 768 : 1024, g2 = special ? 256 : 768;     // workgroups per launch: 3-4 (source) and 3 or 1 (optics) per CU
+                const int g1 = src == 1 ? 768 : 1024, g2 = special ? 512 : 768;     // workgroups per launch: 3-4 (source) and 3 or 1 (optics) per CU
                 int grid1 = nb < g1 ? nb : g1, grid2 = nb < g2 ? nb : g2;
                 HIP_TRY(hipMemsetAsync(ws, 0, 64, stream));
                 hipLaunchKernelGGL(k1, dim3(grid1), dim3(XRT_TILE), lds, stream, ks, a, g);
