@@ -24,8 +24,10 @@
  * do it, and handed over as doubles.
  *
  * Conventions: return value 0 = ok, negative = error (text via xrt_last_error()).
- * The library never throws across the ABI, never allocates on behalf of the
- * caller and never synchronises the device: the caller owns every buffer (device
+ * The library never throws across the ABI, never allocates device memory on behalf
+ * of the caller (it keeps small pinned host caches of jump polynomials) and does not
+ * synchronise the device except in xrt_check / xrt_timing_end (table uploads for mesh
+ * optics are blocking host-to-device copies): the caller owns every buffer (device
  * pointers are ordinary HIP device addresses, e.g. torch tensors' data_ptr()),
  * passes the HIP stream to launch on, and synchronises that stream itself.
  * A handle-free design: every call is self-contained; calls on different
@@ -341,7 +343,10 @@ int xrt_make_image(const xrt_optic_t* optic, int64_t n, const double* rays, cons
                    uint64_t* images, void* stream);
 
 /* Synchronises `stream` and reports conditions the asynchronous calls could only flag on the
- * device (a plasma source that produced more rays than the declared capacity): 0 = clean. */
+ * device: -6 a plasma source produced more rays than the declared capacity; -7 a plasma bundle has an
+ * intensity below one without Poisson statistics (the reference's ValueError,
+ * _XicsrtSourceGeneric.py:193-194); -8 the candidate reserve of the Gaussian wavelength sampler was
+ * exhausted (a > 8 sigma event).  0 = clean. */
 int xrt_check(void* workspace, void* stream);
 
 /* Diagnostic, host only: the MT19937 jump-ahead polynomial g(t) = t^J mod phi(t)
