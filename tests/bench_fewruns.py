@@ -4,7 +4,7 @@ Not a test; run on the GPU box:  python tests/bench_fewruns.py"""
 import sys, os, time, json
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, helpers, bench
+import numpy as np, bench
 from xicsrt_amd import xicsrt_raytrace as xrt, config as xconfig
 
 

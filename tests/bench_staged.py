@@ -4,7 +4,7 @@ python tests/bench_staged.py [runs] [rays]"""
 import sys, os, time, json
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, helpers, bench
+import helpers, bench
 from xicsrt_amd import xicsrt_raytrace as xrt, config as xconfig
 runs = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 rays = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000

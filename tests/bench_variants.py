@@ -2,7 +2,7 @@
 import sys, os, time, json
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, bench
+import bench
 from xicsrt_amd import xicsrt_raytrace as xrt, config as xconfig
 runs, rays = 1000, 1000000
 scenes = {

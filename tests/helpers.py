@@ -5,7 +5,6 @@ The oracle (oracle/libxrt_oracle.so) is test infrastructure; it is loaded only
 from here, from __graft_entry__.smoke() and from bench.py's cpu_baseline leg.
 """
 import ctypes as C
-import glob
 import json
 import os
 import subprocess

@@ -7,7 +7,6 @@ rank the full result, which must equal the single-process result and the
 reference's golden totals (any partition of the runs gives the same sums).
 """
 import os
-import sys
 
 import numpy as np
 import pytest
