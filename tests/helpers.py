@@ -162,3 +162,56 @@ def assert_history_matches_golden(flat, rays, mask, gold, rtol=1e-12):
             scale = np.max(np.abs(g[ok])) if ok.any() else 1.0
             err = np.max(np.abs(h[ok] - g[ok])) if ok.any() else 0.0
             assert err <= rtol * max(scale, 1e-300), '%s at %s: err %.3e (scale %.3e)' % (key, name, err, scale)
+
+
+class OracleDeviceTrace:
+    """
+    Stand-in for xicsrt_raytrace.DeviceTrace on machines without a GPU: same interface, CPU tensors, the
+    oracle as the per-rank compute.  Lets the CPU suite drive the product's own host code paths
+    (raytrace()'s process-group branch, history gathering, saving) end to end; never used by the product.
+    `fail_code`: what status() reports (to test the error agreement between ranks).
+    """
+    fail_code = 0
+
+    def __init__(self, flat):
+        import torch
+        self.torch = torch
+        self.flat = flat
+        self.num_out = torch.zeros(flat.n_elements, dtype=torch.int64)
+        self.images = torch.zeros(max(flat.image_bins, 1), dtype=torch.int64)
+
+    def trace(self, seeds, n_iter, keep_images=True):
+        if len(seeds) == 0:
+            return
+        n, img = oracle_counts(self.flat, [int(s) for s in seeds], int(n_iter))
+        self.num_out += self.torch.from_numpy(n)
+        if keep_images:
+            self.images += self.torch.from_numpy(img)
+
+    def trace_history(self, state, keep_images=True, all_rays=False, on_device=False):
+        key, pos, has_gauss, gauss = state
+        st = xscene.RngState()
+        C.memmove(st.key, np.ascontiguousarray(key, dtype=np.uint32).ctypes.data, 624 * 4)
+        st.pos, st.has_gauss, st.gauss = int(pos), int(has_gauss), float(gauss)
+        n, img, rays, mask, out = oracle_history(self.flat, st, all_rays=True)
+        self.num_out += self.torch.from_numpy(n)
+        if keep_images:
+            self.images += self.torch.from_numpy(img)
+        state_out = (np.ctypeslib.as_array(out.key).copy(), int(out.pos), int(out.has_gauss), float(out.gauss))
+        if on_device:
+            return self.torch.from_numpy(rays.copy()), self.torch.from_numpy(mask.astype(np.uint8)), state_out
+        nn = rays.shape[2] if all_rays else int(mask[0].sum())
+        return rays[:, :, :nn], mask[:, :nn], state_out
+
+    def status(self):
+        return (self.fail_code, 'intensity of less than one encountered. Turn on poisson statistics.') \
+            if self.fail_code else (0, '')
+
+    def raise_status(self):
+        xrt.raise_device_status(*self.status())
+
+    def results(self):
+        self.raise_status()
+        return self.unpack(self.num_out.numpy(), self.images.numpy())
+
+    unpack = xrt.DeviceTrace.unpack       # (bound at import: tests replace xrt.DeviceTrace by this class)

@@ -1,10 +1,13 @@
 """
-N > 1 path on CPU: two processes, gloo backend.  Each rank takes the runs
-`shard_runs` gives it (run i -> rank i mod world, seeds travel with the run
-index), computes its partial histogram/counters (with the CPU oracle standing
-in for the device), and ONE all-reduce of the packed integer vector gives every
-rank the full result, which must equal the single-process result and the
-reference's golden totals (any partition of the runs gives the same sums).
+N > 1 path on CPU: two processes, gloo backend.
+
+1. The exchange step on its own: each rank takes the runs `shard_runs` gives it (run i -> rank i mod world,
+   seeds travel with the run index), computes its partial histogram/counters (with the CPU oracle standing
+   in for the device), and ONE all-reduce of the packed integer vector gives every rank the full result,
+   which must equal the single-process result and the reference's golden totals.
+2. The product's own process-group branch: `xicsrt_amd.raytrace(config)` is called under the group with
+   helpers.OracleDeviceTrace standing in for DeviceTrace (no GPU here), so sharding, the status agreement,
+   the all-reduce, the history gather in run order and the rank-0-only saving are the code that ships.
 """
 import os
 
@@ -40,14 +43,18 @@ def _worker(rank, world, port, name, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('name', ['C_sphere_runs', 'B_mirror_runs'])
-def test_two_ranks_reduce_to_single_process_result(name):
-    world = 2
+def _spawn(fn, world, *args):
     port = 29500 + (os.getpid() % 2000)
     with mp.Manager() as manager:
         ret = manager.dict()
-        mp.spawn(_worker, args=(world, port, name, ret), nprocs=world, join=True)
-        results = dict(ret)
+        mp.spawn(fn, args=(world, port) + args + (ret,), nprocs=world, join=True)
+        return dict(ret)
+
+
+@pytest.mark.parametrize('name', ['C_sphere_runs', 'B_mirror_runs'])
+def test_two_ranks_reduce_to_single_process_result(name):
+    world = 2
+    results = _spawn(_worker, world, name)
     cfg, gold = helpers.load_golden(name)
     config, elements, flat = helpers.build(cfg)
     g = config['general']
@@ -59,3 +66,81 @@ def test_two_ranks_reduce_to_single_process_result(name):
         assert np.array_equal(n, n1) and np.array_equal(i, i1)
     for k, nm in enumerate(flat.names):
         assert int(n1[k]) == int(gold['num_out/' + nm])
+
+
+# ---- the product's raytrace() under a process group ---------------------------------------------
+
+def _summary(out):
+    """Picklable digest of a results dictionary: counters, images, histories."""
+    d = {'meta': {k: int(v['num_out']) for k, v in out['total']['meta'].items()},
+         'image': {k: (None if v is None else np.asarray(v)) for k, v in out['total']['image'].items()},
+         'hist': {}}
+    for group in ('found', 'lost'):
+        for name, rays in out[group]['history'].items():
+            for key in ('origin', 'direction', 'wavelength', 'mask'):
+                d['hist'][(group, name, key)] = np.asarray(rays[key]).copy()
+    return d
+
+
+def _raytrace_worker(rank, world, port, cfg, fail_rank, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    if world > 1:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from xicsrt_amd import xicsrt_raytrace as xrt
+        xrt.DeviceTrace = helpers.OracleDeviceTrace            # no GPU here: the oracle is the per-rank compute
+
+        if fail_rank is not None:
+            class Failing(helpers.OracleDeviceTrace):
+                fail_code = -7 if rank == fail_rank else 0
+            xrt.DeviceTrace = Failing
+        try:
+            out = xrt.raytrace(cfg)
+            ret[rank] = ('ok', _summary(out))
+        except Exception as e:          # noqa: BLE001 - the test asserts on the type name
+            ret[rank] = ('raised', type(e).__name__, str(e))
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+def _config(tmp_path, keep_history, runs=5):
+    import bench
+    cfg = bench.spectrometer_config(4000, runs, seed=7)
+    cfg['general'].update({'keep_history': keep_history, 'history_max_lost': 600, 'number_of_iter': 2,
+                           'save_config': True, 'save_images': False, 'output_path': str(tmp_path),
+                           'output_prefix': 'dist', 'print_results': False})
+    return cfg
+
+
+@pytest.mark.parametrize('keep_history', [False, True])
+def test_raytrace_under_a_process_group_equals_single_process(tmp_path, keep_history):
+    (tmp_path / 'one').mkdir(exist_ok=True)
+    (tmp_path / 'two').mkdir(exist_ok=True)
+    one = _spawn(_raytrace_worker, 1, _config(tmp_path / 'one', keep_history), None)
+    two = _spawn(_raytrace_worker, 2, _config(tmp_path / 'two', keep_history), None)
+    assert one[0][0] == 'ok', one[0]
+    ref = one[0][1]
+    assert ref['meta']['detector'] > 0
+    for rank in (0, 1):
+        assert two[rank][0] == 'ok', two[rank]
+        got = two[rank][1]
+        assert got['meta'] == ref['meta']
+        for k, img in ref['image'].items():
+            assert np.array_equal(got['image'][k], img)
+        assert set(got['hist']) == set(ref['hist'])
+        if keep_history:
+            assert len(ref['hist'][('found', 'detector', 'mask')]) == ref['meta']['detector']
+        for k, arr in ref['hist'].items():
+            assert np.array_equal(got['hist'][k], arr, equal_nan=(arr.dtype.kind == 'f')), k
+    # saving happens once, on rank 0 (a second writer would raise FileExistsError: overwrite is off)
+    assert len([f for f in os.listdir(tmp_path / 'two') if 'config' in f]) == 1
+
+
+def test_every_rank_raises_when_one_device_reports_an_error(tmp_path):
+    (tmp_path / 'err').mkdir()
+    res = _spawn(_raytrace_worker, 2, _config(tmp_path / 'err', False), 1)
+    assert res[1][0] == 'raised' and res[1][1] == 'ValueError' and 'intensity of less than one' in res[1][2]
+    assert res[0][0] == 'raised' and res[0][1] == 'RuntimeError'
+    assert os.listdir(tmp_path / 'err') == []

@@ -46,7 +46,7 @@
 #define XRT_AHEAD    512u       // words every head keeps generated ahead of its read position
 #define XRT_STRETCH  20560      // 19937 + 623 words: what one jump reads
 #define XRT_TILE_COMP 7         // x,y,z, dx,dy,dz, wavelength
-#define XRT_QCAP     384u       // records in the fused kernel's circular ray buffer (127 queued + 256 new)
+#define XRT_QCAP     448u       // records in the fused kernel's circular ray buffer (63 survivors + 127 queued + 256 new)
 
 // --------------------------------------------------------------------------
 // kernel-argument scene (passed by value: uniform, read through scalar loads)
@@ -659,12 +659,14 @@ __device__ __forceinline__ void image_hit(const KOptic& op, const V3& X, unsigne
 // back-to-back scans need no second one.
 // --------------------------------------------------------------------------
 
+// `rotw`: the ranks follow the virtual thread order (tid + 64 * rotw) mod 256, i.e. wave `rotw` holds
+// virtual threads 192.. and wave (4 - rotw) mod 4 comes first (see the wave rotation of the fused kernel).
 __device__ __forceinline__ uint32_t wg_rank(bool flag, uint32_t* wave_tot /*[2][4]*/, int& slot,
-                                            int tid, uint32_t& total)
+                                            int tid, uint32_t& total, uint32_t rotw = 0u)
 {
     unsigned long long b = __ballot(flag);
     uint32_t lane_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
-    uint32_t wave = (uint32_t)tid >> 6;
+    uint32_t wave = (((uint32_t)tid >> 6) + rotw) & 3u;
     uint32_t* wt = wave_tot + slot * 4;
     if ((tid & 63) == 0) wt[wave] = (uint32_t)__popcll(b);
     __syncthreads();
@@ -858,6 +860,25 @@ struct KArgs {
 #ifndef XRT_WAVES_PER_EU
 #define XRT_WAVES_PER_EU 4
 #endif
+#ifndef XRT_ABLATE
+#define XRT_ABLATE 0        // development: > 0 cuts the fused kernel short behind a stage (instruction accounting)
+#endif
+
+// The flattened scene lives in device memory (workspace) and is read through the constant
+// address space: uniform scalar loads (s_load), no kernarg-size limit on the number of optics.
+// Such loads are invariant, so LLVM would hoist all of them out of the tile loop and then spill
+// ~150 scalar registers into vector-register lanes (v_writelane / v_readlane are VALU work in the
+// hot loop).  scene_fresh() hands the same pointer back through an empty asm: loads behind it
+// cannot move above it, which keeps the live ranges of the scene constants inside one stage.
+#define XRT_C4 __attribute__((address_space(4)))
+__device__ __forceinline__ const KScene* scene_fresh(const KScene* p)
+{
+    uint64_t a = (uint64_t)p;
+    asm volatile("" : "+s"(a));
+    return (const KScene*)(const XRT_C4 KScene*)a;
+}
+#define SC  (*scl)
+#define SRC (scl->src)
 
 // HIST: write the per-element history.  VARIANT 0: the lean variant (isotropic
 // cone, shared cone axis, constant or uniform wavelength, plane/sphere, no
@@ -869,7 +890,7 @@ struct KArgs {
 // each unit at the stream position the counts of the earlier segments give.
 template <bool HIST, int VARIANT, bool SEG>
 __global__ __launch_bounds__(XRT_TILE, (VARIANT == 2 ? 2 : XRT_WAVES_PER_EU))
-void xrt_trace_kernel(const KScene sc, const KArgs args)
+void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
 {
     constexpr bool FULL = VARIANT == 1 || VARIANT == 2;
     constexpr bool EXT = VARIANT == 2;
@@ -884,8 +905,8 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
     uint32_t* qaux   = qid + XRT_QCAP;                                                 // [XRT_QCAP] (EXT only)
     uint32_t* rings  = qaux + (EXT ? XRT_QCAP : 0u);                                   // [nh+1][1024]
     const int tid = threadIdx.x;
-    const KSource& S = sc.src;
-    const int64_t N = S.n_rays;
+    const KScene* scl = scene_fresh(scene_g);
+    const int64_t N = SRC.n_rays;
     const int nh = args.n_src_heads;
     uint32_t* stream = rings + nh * XRT_RING;
     uint32_t* small = stream + XRT_RING;
@@ -894,11 +915,17 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
     uint32_t* bcast = small + 8 + 2 * (XRT_DEV_MAX_OPTICS + 2);
 
     int slot = 0;
+    // Wave rotation.  The stages behind a compaction work on n < 256 dense rays, i.e. on the first
+    // ceil(n / 64) *virtual* waves; which hardware wave is virtual wave 0 moves on with every such stage
+    // so that the partial-width stages (Bragg test: 128 rays, elements behind it: a few rays) load the
+    // four SIMDs of the CU evenly instead of always the ones that host waves 0 and 1.
+    uint32_t rotw = 0;
+    auto vtid = [&]() __attribute__((always_inline)) -> uint32_t { return ((uint32_t)tid + 64u * rotw) & 255u; };
 
     // the (single) element that makes a Bragg test on this path, or -1
     int be = -1;
-    for (int e = 0; e < sc.n_optics; e++)
-        if (sc.opt[e].interact == XRT_INTERACT_CRYSTAL && (sc.opt[e].flags & XRT_F_CHECK_BRAGG)) be = e;
+    for (int e = 0; e < SC.n_optics; e++)
+        if (SC.opt[e].interact == XRT_INTERACT_CRYSTAL && (SC.opt[e].flags & XRT_F_CHECK_BRAGG)) be = e;
 
     auto q_store = [&](uint32_t i, const V3& o, const V3& d, double wl, uint32_t id) __attribute__((always_inline)) {
         qbuf[0 * XRT_QCAP + i] = o.x; qbuf[1 * XRT_QCAP + i] = o.y; qbuf[2 * XRT_QCAP + i] = o.z;
@@ -937,7 +964,7 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
 #pragma unroll
             for (int k = 0; k < 6; k++) {
                 hgen[k] = 0; hpos[k] = 0;
-                if ((S.array_used >> k) & 1u) {
+                if ((SRC.array_used >> k) & 1u) {
                     const KStream* src = SEG ? args.heads + (size_t)run * args.run_stride + (size_t)seg * nh + h
                                              : args.heads + (size_t)run * nh + h;
                     uint32_t* r = rings + h * XRT_RING;
@@ -977,7 +1004,7 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
         const uint64_t s_next0 = uni64(st_in->next), s_gen0 = uni64(st_in->gen);
         uint32_t sgen = (uint32_t)s_gen0, spos = (uint32_t)s_next0;
         uint64_t s_used = 0;
-        uint32_t qhead = 0, qcount = 0;
+        uint32_t qhead = 0, qcount = 0, bcount = 0;
         uint32_t n_candidates = 0;
         if (tid < XRT_DEV_MAX_OPTICS + 1) cnt[tid] = 0ULL;
         __syncthreads();
@@ -990,7 +1017,7 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
             int h = 0;
 #pragma unroll
             for (int k = 0; k < 6; k++) {
-                if ((S.array_used >> k) & 1u) {
+                if ((SRC.array_used >> k) & 1u) {
                     uint32_t avail = hgen[k] - hpos[k];
                     if (avail < XRT_AHEAD) {
                         uint32_t chunk = XRT_AHEAD - avail;
@@ -1022,7 +1049,7 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
             bool sh = false;
 #pragma unroll
             for (int k = 0; k < 6; k++)
-                if ((S.array_used >> k) & 1u) sh = sh || ((hgen[k] - hpos[k]) < XRT_AHEAD);
+                if ((SRC.array_used >> k) & 1u) sh = sh || ((hgen[k] - hpos[k]) < XRT_AHEAD);
             return sh;
         };
 
@@ -1036,19 +1063,21 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
         }
 
         // Bragg angle shared by all rays when the wavelength is one constant
-        const bool wl_shared = (S.wavelength_dist == XRT_WL_CONST) && !S.has_velocity;
+        const bool wl_shared = (SRC.wavelength_dist == XRT_WL_CONST) && !SRC.has_velocity;
         double bragg_shared = 0.0;
-        if (wl_shared && be >= 0) bragg_shared = asin((1.0 * S.wavelength) / sc.opt[be].two_d);
+        if (wl_shared && be >= 0) bragg_shared = asin((1.0 * SRC.wavelength) / SC.opt[be].two_d);
 
         // Elements without a Bragg test, starting at element `e` with rays held by the threads
         // tid < n_in (`fresh` = the rays still have to be intersected with element e; otherwise
         // `alive` already says which of them left element e).  Runs up to (not including) the
         // Bragg element, where it returns true with the candidates' state for the caller to queue.
         // `scratch`: first free record of the circular buffer, used for the compactions.
+        // `rot_in`: rotation the incoming rays are laid out with (0 for a source tile: ray order = thread order).
         auto plain_elements = [&](int e, bool fresh, uint32_t n_in, bool& have, bool& alive, Ray& ray, V3& X,
-                                  uint32_t& id, int& aux, uint32_t scratch) __attribute__((always_inline)) -> int {
-            for (; e < sc.n_optics && n_in > 0; e++) {
-                const KOptic& op = sc.opt[e];
+                                  uint32_t& id, int& aux, uint32_t scratch, uint32_t rot_in) __attribute__((always_inline)) -> int {
+            for (; e < SC.n_optics && n_in > 0; e++) {
+                scl = scene_fresh(scene_g);
+                const KOptic& op = SC.opt[e];
                 if (fresh) {
                     alive = false;
                     // (the EXT parts are discarded statements in the other variants: even dead code here
@@ -1125,16 +1154,20 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
                 // is found after it, on dense lanes
                 uint32_t n_out;
                 mt_step();
-                uint32_t rank = wg_rank(alive, wave_tot, slot, tid, n_out);
+                uint32_t rank = wg_rank(alive, wave_tot, slot, tid, n_out, rot_in);
                 if (tid == 0 && !counting) cnt[e + 1] += n_out;
                 const bool image = (op.flags & XRT_F_IMAGE) && args.images && !counting;
-                if (e + 1 < sc.n_optics && n_out > 0) {
+                if (e + 1 < SC.n_optics && n_out > 0) {
                     if (alive) q_store(q_wrap(scratch + rank), ray.o, ray.d, ray.wl, id);
                     mt_step();
                     __syncthreads();
-                    have = (uint32_t)tid < n_out;
+                    // the survivors move on to the waves behind the ones that held the incoming rays
+                    rotw = (rotw + ((n_in + 63u) >> 6)) & 3u;
+                    rot_in = rotw;
+                    const uint32_t vt = vtid();
+                    have = vt < n_out;
                     if (have) {
-                        q_load(q_wrap(scratch + (uint32_t)tid), ray.o, ray.d, ray.wl, id);
+                        q_load(q_wrap(scratch + vt), ray.o, ray.d, ray.wl, id);
                         if (image) image_hit(op, ray.o, args.images);
                     }
                     // the next write into the buffer happens behind the next scan's barrier
@@ -1146,10 +1179,42 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
             return -1;
         };
 
+        // The survivors of the Bragg test wait in a second queue of the same circular buffer (bcount records
+        // right below the candidates' head) until 64 of them are there: the elements behind the crystal then
+        // run on a full wave once per ~64 reflected rays instead of on a handful of lanes after every batch
+        // (that stage is a long dependent chain -- pixel index, plane intersection, bounds, pixel index --
+        // during which the other waves of the workgroup sit at barriers).  Their order does not matter:
+        // counters and pixel bins are sums, history rows are written by ray index.
+        auto drain_survivors = [&](bool all) __attribute__((always_inline)) {
+            while (bcount >= 64u || (all && bcount > 0u)) {
+                const uint32_t n = bcount < 64u ? bcount : 64u;
+                mt_step();
+                __syncthreads();                                  // survivor records visible
+                scl = scene_fresh(scene_g);
+                const KOptic& opb = SC.opt[be];
+                const uint32_t vt = vtid();
+                bool have_b = vt < n, alive_b = false;
+                Ray rb;
+                V3 Xb;
+                uint32_t idb = 0;
+                int auxb = 0;
+                Xb.x = Xb.y = Xb.z = 0.0;
+                rb.o = Xb; rb.d = Xb; rb.wl = 0.0;
+                if (have_b) {
+                    q_load(q_wrap(qhead + XRT_QCAP - bcount + vt), rb.o, rb.d, rb.wl, idb);
+                    if ((opb.flags & XRT_F_IMAGE) && args.images) image_hit(opb, rb.o, args.images);
+                }
+                bcount -= n;
+                plain_elements(be + 1, true, n, have_b, alive_b, rb, Xb, idb, auxb, q_wrap(qhead + qcount), rotw);
+                rotw = (rotw + 1u) & 3u;
+            }
+        };
+
         // ---- tiles of 256 rays in original order ----------------------------
         for (int64_t i0 = ray_lo; i0 < ray_hi; i0 += XRT_TILE) {
             const int64_t left = ray_hi - i0;
             const uint32_t n_tile = left < XRT_TILE ? (uint32_t)left : (uint32_t)XRT_TILE;
+            scl = scene_fresh(scene_g);
 
             // everything this tile consumes must be generated: normally already
             // done behind the previous tile's barriers
@@ -1161,7 +1226,7 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
 #pragma unroll
                 for (int k = 0; k < 6; k++) {
                     u[k] = 0.0;
-                    if ((S.array_used >> k) & 1u) {
+                    if ((SRC.array_used >> k) & 1u) {
                         const uint32_t* r = rings + h * XRT_RING;
                         uint32_t n = hpos[k] + 2u * (uint32_t)tid;
                         u[k] = mt_double(r[n & XRT_RMASK], r[(n + 1u) & XRT_RMASK]);
@@ -1180,7 +1245,14 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
             if constexpr (SEG && FULL) {
                 if (args.wl_array) u[5] = have ? args.wl_array[(size_t)run * (size_t)N + (size_t)id] : 0.0;
             }
-            source_ray<FULL>(S, u, ray);
+#if XRT_ABLATE >= 4
+            have = have && (u[3] + u[4] < -1.0);
+            if (have)
+#endif
+            source_ray<FULL>(SRC, u, ray);
+#if XRT_ABLATE == 3
+            have = have && (id == 0xffffffffu);
+#endif
             if constexpr (SEG && LEANWL) ray.wl = have ? args.wl_array[(size_t)run * (size_t)N + (size_t)id] : 0.0;
             if (tid == 0 && !counting) cnt[0] += n_tile;
             if (HIST && have && !counting) hist_write(args.hist, args.hmask, N, 0, id, ray.o, ray.d, ray.wl, true);
@@ -1188,7 +1260,7 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
             // elements in config order (objects/_Dispatcher.py:166-196) up to the Bragg element
             if (counting) {
                 // mode 1: only the number of rays that reach the Bragg test matters
-                const int stop = plain_elements(0, true, n_tile, have, alive, ray, X, id, aux, 0u);
+                const int stop = plain_elements(0, true, n_tile, have, alive, ray, X, id, aux, 0u, 0u);
                 if (stop >= 0) {
                     uint32_t n_a;
                     mt_step();
@@ -1197,13 +1269,18 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
                 }
                 continue;
             }
-            const int stop = plain_elements(0, true, n_tile, have, alive, ray, X, id, aux, q_wrap(qhead + qcount));
+            const int stop = plain_elements(0, true, n_tile, have, alive, ray, X, id, aux, q_wrap(qhead + qcount), 0u);
+#if XRT_ABLATE == 2
+            alive = alive && (id == 0xffffffffu);
+#endif
             if (stop >= 0) {
                 // queue the candidates in ray order: ordered live rank -> FIFO position
                 // (a locally traced element queues its local-frame point and direction)
+                // (elements in front of the Bragg element may have moved the rays to rotated waves)
+                const uint32_t rot_here = (stop > 0) ? rotw : 0u;
                 uint32_t n_a;
                 mt_step();
-                uint32_t rank = wg_rank(alive, wave_tot, slot, tid, n_a);
+                uint32_t rank = wg_rank(alive, wave_tot, slot, tid, n_a, rot_here);
                 if constexpr (EXT) {
                     if (alive) {
                         q_store(q_wrap(qhead + qcount + rank), X, ray.d, ray.wl, id);
@@ -1218,22 +1295,25 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
             // ---- Bragg test + the remaining elements, 128 queued rays at a time -----------
             const bool last_tile = (i0 + XRT_TILE >= ray_hi);
             while (be >= 0 && (qcount >= 128u || (last_tile && qcount > 0u))) {
-                const KOptic& op = sc.opt[be];
+                scl = scene_fresh(scene_g);
+                const KOptic& op = SC.opt[be];
                 const uint32_t nb = qcount < 128u ? qcount : 128u;
                 // n uniforms from the stream head (np.random.uniform(0,1,n_live), optics/_InteractCrystal.py:189)
                 while ((sgen - spos) < 2u * nb) { mt_step(); __syncthreads(); }
                 mt_step();
                 __syncthreads();                                  // queue records visible
-                have = (uint32_t)tid < nb;
+                rotw = (rotw + 1u) & 3u;                          // this batch: virtual waves 0,1 = hardware waves -rotw, 1-rotw
+                const uint32_t vt = vtid();
+                have = vt < nb;
                 alive = false;
                 if constexpr (EXT) {
                     const bool local = (op.flags & XRT_F_TRACE_LOCAL) != 0;
                     if (have) {
-                        q_load(q_wrap(qhead + (uint32_t)tid), X, ray.d, ray.wl, id);
+                        q_load(q_wrap(qhead + vt), X, ray.d, ray.wl, id);
                         V3 nrm;
-                        if (op.shape == XRT_SHAPE_MESH) nrm = mesh_normal(op.mesh, X.x, X.y, (int)qaux[q_wrap(qhead + (uint32_t)tid)]);
+                        if (op.shape == XRT_SHAPE_MESH) nrm = mesh_normal(op.mesh, X.x, X.y, (int)qaux[q_wrap(qhead + vt)]);
                         else nrm = surface_normal<FULL>(op, X);
-                        uint32_t n = spos + 2u * (uint32_t)tid;
+                        uint32_t n = spos + 2u * vt;
                         double test = 0.0 + (1.0 - 0.0) * mt_double(stream[n & XRT_RMASK], stream[(n + 1u) & XRT_RMASK]);
                         alive = bragg_accept(op, ray, nrm, test, wl_shared, bragg_shared);
                         if (HIST && !alive) {
@@ -1261,11 +1341,14 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
                     }
                 } else {
                     if (have) {
-                        q_load(q_wrap(qhead + (uint32_t)tid), X, ray.d, ray.wl, id);
+                        q_load(q_wrap(qhead + vt), X, ray.d, ray.wl, id);
                         V3 nrm = surface_normal<FULL>(op, X);
-                        uint32_t n = spos + 2u * (uint32_t)tid;
+                        uint32_t n = spos + 2u * vt;
                         double test = 0.0 + (1.0 - 0.0) * mt_double(stream[n & XRT_RMASK], stream[(n + 1u) & XRT_RMASK]);
                         alive = bragg_accept(op, ray, nrm, test, wl_shared, bragg_shared);
+#if XRT_ABLATE == 1
+                        alive = alive && (id == 0xffffffffu);
+#endif
                         if (HIST && !alive) hist_write(args.hist, args.hmask, N, be + 1, id, X, ray.d, ray.wl, false);
                         if (alive) {
                             ray.o = X;
@@ -1279,11 +1362,33 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
                 }
                 spos += 2u * nb;
                 s_used += 2ull * nb;
-                const uint32_t freed = qhead;                     // these records are free again: compaction scratch
+                const uint32_t head_old = qhead;
                 qhead = q_wrap(qhead + nb);
                 qcount -= nb;
-                plain_elements(be, false, nb, have, alive, ray, X, id, aux, freed);
+                // ---- the reflected rays join the survivor queue, which sits right below the candidates' head:
+                // [qhead - bcount, qhead).  The batch just freed [head_old, qhead); the new survivors go to its
+                // upper end by ordered rank, and the (< 64) survivors left from earlier batches are moved up
+                // behind them by a wave that has nothing else to do in this stage (virtual wave 3): it reads
+                // them in front of the scan's barrier and writes them behind it.
+                V3 mo, md;
+                double mwl = 0.0;
+                uint32_t mid = 0;
+                mo.x = mo.y = mo.z = 0.0; md = mo;
+                const bool mover = (vt >= 192u) && (vt - 192u < bcount);
+                if (mover) q_load(q_wrap(head_old + XRT_QCAP - bcount + (vt - 192u)), mo, md, mwl, mid);
+                uint32_t n_s;
+                mt_step();
+                const uint32_t srank = wg_rank(alive, wave_tot, slot, tid, n_s, rotw);
+                if (tid == 0) cnt[be + 1] += n_s;
+                if (alive) q_store(q_wrap(qhead + XRT_QCAP - n_s + srank), ray.o, ray.d, ray.wl, id);
+                if (mover && n_s < nb) q_store(q_wrap(qhead + XRT_QCAP - n_s - bcount + (vt - 192u)), mo, md, mwl, mid);
+                bcount += n_s;
+                rotw = (rotw + 2u) & 3u;
+                // ---- survivors: 64 at a time (everything that is left behind the run's last batch) through
+                // the elements behind the Bragg element, on one full wave
+                drain_survivors(last_tile && qcount == 0u);
             }
+            if (be >= 0 && last_tile) drain_survivors(true);
         }
 
         // ---- run done: counters out, stream head back to memory ---------------
@@ -1295,7 +1400,7 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
             continue;
         }
         if (!HIST) while ((sgen - spos) < XRT_AHEAD) { mt_step(); __syncthreads(); }
-        if (tid <= sc.n_optics && cnt[tid] != 0ULL) atomicAdd(&args.num_out[tid], cnt[tid]);
+        if (tid <= SC.n_optics && cnt[tid] != 0ULL) atomicAdd(&args.num_out[tid], cnt[tid]);
         // the stream head goes back to memory: always for a whole run; of a segmented run only the
         // last segment knows where the run's stream ends
         if (!SEG || seg + 1u == (uint32_t)args.n_seg) {
@@ -1308,6 +1413,9 @@ void xrt_trace_kernel(const KScene sc, const KArgs args)
         __syncthreads();
     }
 }
+
+#undef SC
+#undef SRC
 
 #include "xrt_staged.inc"
 
@@ -1418,7 +1526,7 @@ extern "C" int xrt_scene_check(const xrt_scene_t* sc)
     return 0;
 }
 
-// workspace layout: [run counter 256 B][apertures][voigt tables][KState in][seeds][streams][heads]
+// workspace layout: [run counter 256 B][KScene][apertures][voigt tables][KState in][seeds][streams][heads]
 static int count_heads(const xrt_scene_t* sc)
 {
     int n = 2;      // the two angular arrays are always needed
@@ -1427,7 +1535,8 @@ static int count_heads(const xrt_scene_t* sc)
     return n;
 }
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
-static size_t ws_off_apertures() { return 256; }
+static size_t ws_off_scene() { return 256; }
+static size_t ws_off_apertures() { return ws_off_scene() + al256(sizeof(KScene)); }
 static size_t ws_off_voigt() { return ws_off_apertures() + sizeof(xrt_aperture_t) * XRT_MAX_APERTURES * XRT_DEV_MAX_OPTICS; }
 static size_t ws_off_state(const xrt_scene_t* sc)
 {
@@ -1850,9 +1959,37 @@ static int upload_tables(const xrt_scene_t* sc, char* ws, hipStream_t stream)
     return 0;
 }
 
-template <bool HIST, int VARIANT, bool SEG = false>
-static int launch_variant(const KScene& ks, const KArgs& a, int n_runs, size_t lds, hipStream_t stream)
+// The flattened scene goes to the workspace through the kernel-argument path (copied by the runtime
+// at launch, ordered on the stream, no host buffer whose lifetime would matter), 2 KB at a time.
+struct KBlob { uint32_t w[512]; };
+__global__ void xrt_put_kernel(uint32_t* dst, const KBlob blob, int n_words)
 {
+    for (int i = threadIdx.x; i < n_words; i += blockDim.x) dst[i] = blob.w[i];
+}
+static int upload_scene(const KScene& ks, char* ws, hipStream_t stream)
+{
+    static_assert(sizeof(KScene) % 4 == 0, "scene size");
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&ks);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(ws + ws_off_scene());
+    const int total = (int)(sizeof(KScene) / 4);
+    for (int o = 0; o < total; o += 512) {
+        KBlob b;
+        const int n = (total - o) < 512 ? (total - o) : 512;
+        memcpy(b.w, src + o, (size_t)n * 4);
+        hipLaunchKernelGGL(xrt_put_kernel, dim3(1), dim3(256), 0, stream, dst + o, b, n);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+static const KScene* device_scene(char* ws) { return reinterpret_cast<const KScene*>(ws + ws_off_scene()); }
+
+template <bool HIST, int VARIANT, bool SEG = false>
+static int launch_variant(const KScene* ks, const KArgs& a, int n_runs, size_t lds, hipStream_t stream)
+{
+#ifdef XRT_DEV_ONLY_LEAN     // development builds: only the lean kernel is compiled (seconds instead of a minute)
+    if constexpr (HIST || VARIANT != 0 || SEG) return fail(-3, "%s", "development build: lean kernel only");
+    else {
+#endif
     auto kern = xrt_trace_kernel<HIST, VARIANT, SEG>;
     // attribute and occupancy queries cost ~0.1 ms each: once per (device, LDS size) and instantiation
     static thread_local int c_dev = -1, c_cus = 256, c_per_cu = 1;
@@ -1884,6 +2021,9 @@ static int launch_variant(const KScene& ks, const KArgs& a, int n_runs, size_t l
     HIP_TRY(hipGetLastError());
     if (ti >= 0) HIP_TRY(hipEventRecord(timing_ev[ti][1], stream));
     return 0;
+#ifdef XRT_DEV_ONLY_LEAN
+    }
+#endif
 }
 
 // one iteration of every run: position the heads (jump-ahead when every stream is in the
@@ -1898,6 +2038,9 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
     KStream* streams = reinterpret_cast<KStream*>(ws + ws_off_streams(sc, n_runs));
     KStream* heads = reinterpret_cast<KStream*>(ws + ws_off_heads(sc, n_runs));
     const int64_t N = ks.src.n_rays;
+#ifdef XRT_DEV_ONLY_LEAN
+    if (needs_staged(sc) || force_staged) return fail(-3, "%s", "development build: lean kernel only");
+#else
     if (needs_staged(sc) || force_staged) {
         // general path: array-at-a-time passes with one sequential stream head per run
         KStaged g;
@@ -1965,6 +2108,7 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
         if (ti >= 0) HIP_TRY(hipEventRecord(timing_ev[ti][1], stream));
         return 0;
     }
+#endif
     const SegPlan plan = ahead > 0 ? plan_segments(sc, n_runs) : SegPlan{1, 0, 0, 0, 0};
     if (seg_active(plan)) {
         // ---- segmented runs -------------------------------------------------------------------------
@@ -2080,14 +2224,14 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
             a.mode = mode;
             HIP_TRY(hipMemsetAsync(ws, 0, 64, stream));
             int st;
-            if (hist) st = variant == 3 ? launch_variant<true, 3, true>(ks, a, n_runs, lds, stream)
-                         : variant == 2 ? launch_variant<true, 2, true>(ks, a, n_runs, lds, stream)
-                         : variant == 1 ? launch_variant<true, 1, true>(ks, a, n_runs, lds, stream)
-                                        : launch_variant<true, 0, true>(ks, a, n_runs, lds, stream);
-            else      st = variant == 3 ? launch_variant<false, 3, true>(ks, a, n_runs, lds, stream)
-                         : variant == 2 ? launch_variant<false, 2, true>(ks, a, n_runs, lds, stream)
-                         : variant == 1 ? launch_variant<false, 1, true>(ks, a, n_runs, lds, stream)
-                                        : launch_variant<false, 0, true>(ks, a, n_runs, lds, stream);
+            if (hist) st = variant == 3 ? launch_variant<true, 3, true>(device_scene(ws), a, n_runs, lds, stream)
+                         : variant == 2 ? launch_variant<true, 2, true>(device_scene(ws), a, n_runs, lds, stream)
+                         : variant == 1 ? launch_variant<true, 1, true>(device_scene(ws), a, n_runs, lds, stream)
+                                        : launch_variant<true, 0, true>(device_scene(ws), a, n_runs, lds, stream);
+            else      st = variant == 3 ? launch_variant<false, 3, true>(device_scene(ws), a, n_runs, lds, stream)
+                         : variant == 2 ? launch_variant<false, 2, true>(device_scene(ws), a, n_runs, lds, stream)
+                         : variant == 1 ? launch_variant<false, 1, true>(device_scene(ws), a, n_runs, lds, stream)
+                                        : launch_variant<false, 0, true>(device_scene(ws), a, n_runs, lds, stream);
             if (st) return st;
         }
         return 0;
@@ -2127,11 +2271,11 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
     const int variant = needs_ext(sc) ? 2 : (needs_full(sc) ? 1 : 0);
     const size_t lds = lds_bytes(nh, variant == 2);
     if (hist) {
-        if (variant == 2) return launch_variant<true, 2>(ks, a, n_runs, lds, stream);
-        return variant == 1 ? launch_variant<true, 1>(ks, a, n_runs, lds, stream) : launch_variant<true, 0>(ks, a, n_runs, lds, stream);
+        if (variant == 2) return launch_variant<true, 2>(device_scene(ws), a, n_runs, lds, stream);
+        return variant == 1 ? launch_variant<true, 1>(device_scene(ws), a, n_runs, lds, stream) : launch_variant<true, 0>(device_scene(ws), a, n_runs, lds, stream);
     }
-    if (variant == 2) return launch_variant<false, 2>(ks, a, n_runs, lds, stream);
-    return variant == 1 ? launch_variant<false, 1>(ks, a, n_runs, lds, stream) : launch_variant<false, 0>(ks, a, n_runs, lds, stream);
+    if (variant == 2) return launch_variant<false, 2>(device_scene(ws), a, n_runs, lds, stream);
+    return variant == 1 ? launch_variant<false, 1>(device_scene(ws), a, n_runs, lds, stream) : launch_variant<false, 0>(device_scene(ws), a, n_runs, lds, stream);
 }
 
 // diagnostic: g(t) = t^J mod phi(t) as 624 words (bit j of word j/32 = g_j); host only
@@ -2166,6 +2310,8 @@ extern "C" int xrt_trace(const xrt_scene_t* sc, const uint32_t* seeds, int32_t n
     st = upload_meshes(sc, ws, n_runs, &ks, stream);
     if (st) return st;
     st = upload_plasma(sc, ws, n_runs, &ks, stream);
+    if (st) return st;
+    st = upload_scene(ks, ws, stream);
     if (st) return st;
     KArgs a;
     memset(&a, 0, sizeof(a));
@@ -2206,6 +2352,8 @@ extern "C" int xrt_trace_history(const xrt_scene_t* sc, const xrt_rng_state_t* s
     st = upload_meshes(sc, ws, 1, &ks, stream);
     if (st) return st;
     st = upload_plasma(sc, ws, 1, &ks, stream);
+    if (st) return st;
+    st = upload_scene(ks, ws, stream);
     if (st) return st;
     KArgs a;
     memset(&a, 0, sizeof(a));

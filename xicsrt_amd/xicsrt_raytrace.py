@@ -214,6 +214,18 @@ def rng_state_from_seed(seed):
     return st[1].astype(np.uint32), int(st[2]), int(st[3]), float(st[4])
 
 
+def raise_device_status(code, message):
+    """Turn a device status (DeviceTrace.status) into the exception the reference raises for it."""
+    if code == 0:
+        return
+    if code in (-6, -7):
+        # conditions the reference reports with ValueError while it builds the bundle sources
+        # (_XicsrtSourceGeneric.py:193-194, _XicsrtPlasmaGeneric.py:277-281)
+        raise ValueError(message)
+    from .capi import DeviceLibraryError
+    raise DeviceLibraryError('xrt_check failed (%d): %s' % (code, message))
+
+
 class DeviceTrace:
     """Owns the device buffers of one flattened scene and issues the C ABI calls."""
 
@@ -273,6 +285,9 @@ class DeviceTrace:
                                             rays.data_ptr(), mask.data_ptr(), st_out.data_ptr(),
                                             ws.data_ptr(), need, stream)
         self.capi.check(status, 'xrt_trace_history')
+        # every xrt_trace_history call starts with a clean status word: read it now, or a capacity overflow /
+        # "intensity of less than one" of this iteration would be overwritten by the next one
+        self.raise_status()
         t.cuda.current_stream().synchronize()
         out = xscene.RngState.from_buffer_copy(st_out.cpu().numpy().tobytes())
         state_out = (np.ctypeslib.as_array(out.key).copy(), int(out.pos), int(out.has_gauss), float(out.gauss))
@@ -283,15 +298,24 @@ class DeviceTrace:
             n = int(mask_h[0].sum())    # plasma sources: the ray count is drawn, n_rays is the capacity
         return rays.cpu().numpy()[:, :, :n], mask_h[:, :n], state_out
 
+    def status(self):
+        """(code, message) of the device status word of the calls issued so far (synchronises the stream);
+        code 0 = fine, -6 plasma ray capacity exceeded, -7 'intensity of less than one', -8 Gaussian
+        wavelength candidates exhausted (include/xicsrt_hip.h, xrt_check)."""
+        if self._ws is None:
+            return 0, ''
+        code = int(self.lib.xrt_check(self._ws.data_ptr(), self.torch.cuda.current_stream().cuda_stream))
+        if code == 0:
+            return 0, ''
+        msg = self.lib.xrt_last_error()
+        return code, (msg.decode() if msg else '?')
+
+    def raise_status(self):
+        raise_device_status(*self.status())
+
     def results(self):
         """Host copies (synchronises the stream): num_out list, {optic: image or None}."""
-        if self._ws is not None:
-            status = self.lib.xrt_check(self._ws.data_ptr(), self.torch.cuda.current_stream().cuda_stream)
-            if status in (-6, -7):
-                # conditions the reference reports with ValueError while it builds the bundle sources
-                # (_XicsrtSourceGeneric.py:193-194, _XicsrtPlasmaGeneric.py:277-281)
-                raise ValueError(self.lib.xrt_last_error().decode())
-            self.capi.check(status, 'xrt_check')
+        self.raise_status()
         self.torch.cuda.current_stream().synchronize()
         return self.unpack(self.num_out.cpu().numpy(), self.images.cpu().numpy())
 
@@ -558,12 +582,10 @@ def _raytrace_runs(config, run_indices, seeds, internal, per_run_images=False):
         max_lost = _max_lost_iter(general, internal)
         outputs = []
         for i, s in zip(run_indices, my_seeds):
-            outputs.append(_run_with_history(config, elements, device, s, max_lost))
+            outputs.append((i, _run_with_history(config, elements, device, s, max_lost)))
             if after_run:
                 after_run(i)
-        if not outputs:
-            return None, device, config
-        return combine_raytrace(outputs), device, config
+        return outputs, device, config
     if after_run:
         for i, s in zip(run_indices, my_seeds):
             device.trace([s], general['number_of_iter'], general['keep_images'])
@@ -587,43 +609,79 @@ def _finish(output, config_user_general):
     return output
 
 
+def _history_payload(single):
+    """What travels between ranks of one run's history: the found / lost ray dictionaries only."""
+    return {group: {name: {k: np.asarray(v) for k, v in rays.items()}
+                    for name, rays in single[group]['history'].items()} for group in ('found', 'lost')}
+
+
 def raytrace(config):
     """
     Perform `number_of_runs` ray-tracing runs of `number_of_iter` iterations each
     and return the combined results dictionary.
 
     When a torch.distributed process group is initialised (one process per
-    GPU) the runs are sharded over the ranks and the integer histogram and
-    counters are summed with one all-reduce (RCCL); every rank returns the
-    full result (histories, if kept, are those of the local runs).
+    GPU) the runs are sharded over the ranks (run i -> rank i mod world).  The
+    exchange step: one all-reduce (RCCL) of the integer vector [num_out | image
+    bins], preceded by a one-word all-reduce of the device status so that every
+    rank raises when any rank's device reported a condition the reference
+    raises for; histories, if kept, are gathered and concatenated in run order
+    (xicsrt_raytrace.py:359-390), so every rank returns what a single process
+    returns.  Files are written and the summary is printed by rank 0 only.
     """
     config_in = xconfig.get_config(config)
     general = config_in['general']
     num_runs = general['number_of_runs']
     seeds = run_seeds(general['random_seed'], num_runs)
     dist, rank, world = _dist()
+    distributed = dist is not None and world > 1
+    if distributed and general['random_seed'] is None:
+        # every rank must use the same (random) seeds: rank 0's
+        box = [seeds]
+        dist.broadcast_object_list(box, src=0)
+        seeds = box[0]
     indices = shard_runs(num_runs, rank, world)
 
-    hist_output, device, cfg = _raytrace_runs(copy.deepcopy(config_in), indices, seeds, internal=True,
+    # per-run image files carry the run number in their names: each rank writes those of its own runs
+    run_outputs, device, cfg = _raytrace_runs(copy.deepcopy(config_in), indices, seeds, internal=True,
                                               per_run_images=bool(general['save_images']))
 
     t = device.torch
-    if dist is not None and world > 1:
+    if distributed:
+        code, message = device.status()
+        flag = t.tensor([1 if code != 0 else 0], dtype=t.int64, device=device.num_out.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()) != 0:
+            raise_device_status(code, message)
+            raise RuntimeError('another rank reported a device error; results are not valid')
         packed = pack_counts(device.num_out, device.images)
         dist.all_reduce(packed, op=dist.ReduceOp.SUM)
         num_out, images = unpack_counts(packed, device.num_out.numel())
         meta, image = device.unpack(num_out.cpu().numpy(), images.cpu().numpy())
+        if general['keep_history']:
+            mine = [(i, _history_payload(single)) for i, single in run_outputs]
+            gathered = [None] * world
+            dist.all_gather_object(gathered, mine)
+            run_outputs = []
+            for i, payload in sorted((item for part in gathered for item in part), key=lambda item: item[0]):
+                single = _empty_output(cfg)
+                single['total']['meta'] = {name: {'num_out': 0} for name in meta}
+                for group in ('found', 'lost'):
+                    single[group]['history'] = payload[group]
+                run_outputs.append((i, single))
     else:
         meta, image = device.results()
 
     output = _empty_output(cfg)
-    if hist_output is not None:
-        output = hist_output
+    if run_outputs:
+        output = combine_raytrace([single for _, single in run_outputs])
         output['config'] = cfg
     output['total']['meta'] = meta if general['keep_meta'] else {}
     output['total']['image'] = image if general['keep_images'] else {}
     output['config']['general']['output_run_suffix'] = general['output_run_suffix']
     output['config']['general']['random_seed'] = general['random_seed']
+    if distributed and rank != 0:
+        return output
     return _finish(output, general)
 
 
@@ -647,9 +705,9 @@ def raytrace_single(config, _internal=False):
     if seed is None:
         seed = int.from_bytes(os.urandom(4), 'little')
     saved_runs = general['number_of_runs']
-    hist_output, device, cfg = _raytrace_runs(copy.deepcopy(config_in), [0], [seed], internal=_internal)
+    run_outputs, device, cfg = _raytrace_runs(copy.deepcopy(config_in), [0], [seed], internal=_internal)
     meta, image = device.results()
-    output = hist_output if hist_output is not None else _empty_output(cfg)
+    output = combine_raytrace([single for _, single in run_outputs]) if run_outputs else _empty_output(cfg)
     output['config'] = cfg
     output['total']['meta'] = meta if general['keep_meta'] else {}
     output['total']['image'] = image if general['keep_images'] else {}
