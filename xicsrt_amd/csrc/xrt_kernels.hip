@@ -955,26 +955,53 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
         const int64_t ray_hi = SEG ? ((ray_lo + args.seg_len < N) ? ray_lo + args.seg_len : N) : N;
 
         // ---- load the positioned heads and the stream head ----------------
-        // gen/pos are kept modulo 2^32 (ring slots only need the low 10 bits,
-        // differences stay < 2^11); the stream's 64-bit position is rebuilt
-        // from the number of words consumed.
-        uint32_t hgen[6], hpos[6];
+        // The source heads advance in lockstep (512 words per tile each), so they share one position:
+        // every ring is rotated while it is loaded so that the head's next word sits in slot 0.  A tile's
+        // words then occupy one half of every ring ([0,512) or [512,1024), alternating), all heads use the
+        // same LDS offsets (the ring number goes into the instruction's immediate offset), and the next
+        // tile's half is generated in three fixed chunks of 171, 171 and 170 words (<= 227 are independent).
         {
+            uint32_t havail[6];
             int h = 0;
 #pragma unroll
             for (int k = 0; k < 6; k++) {
-                hgen[k] = 0; hpos[k] = 0;
+                havail[k] = XRT_AHEAD;
                 if ((SRC.array_used >> k) & 1u) {
                     const KStream* src = SEG ? args.heads + (size_t)run * args.run_stride + (size_t)seg * nh + h
                                              : args.heads + (size_t)run * nh + h;
                     uint32_t* r = rings + h * XRT_RING;
-                    for (int i = tid; i < (int)XRT_RING; i += XRT_TILE) r[i] = src->ring[i];
-                    hgen[k] = uni32((uint32_t)src->gen);
-                    hpos[k] = uni32((uint32_t)src->next);
+                    const uint32_t nx = uni32((uint32_t)src->next), gn = uni32((uint32_t)src->gen);
+                    for (int i = tid; i < (int)XRT_RING; i += XRT_TILE) r[((uint32_t)i - nx) & XRT_RMASK] = src->ring[i];
+                    havail[h] = gn - nx;
                     h++;
                 }
             }
+            __syncthreads();
+            // A head arrives with 0 (jump-ahead, sequential walk) to 624 words generated beyond its position;
+            // each is brought to at least one tile's worth from where IT stands (its ring holds nothing older
+            // than 1024 words behind its own front).
+            bool again = true;
+            while (again) {
+                again = false;
+#pragma unroll
+                for (int hh = 0; hh < 6; hh++) {
+                    if (hh < nh && havail[hh] < XRT_AHEAD) {
+                        uint32_t chunk = XRT_AHEAD - havail[hh];
+                        if (chunk > 227u) chunk = 227u;
+                        if ((uint32_t)tid < chunk) {
+                            uint32_t* r = rings + hh * XRT_RING;
+                            const uint32_t n = havail[hh] + (uint32_t)tid;
+                            r[n & XRT_RMASK] = mt_mix(r[(n - 624u) & XRT_RMASK], r[(n - 623u) & XRT_RMASK], r[(n - 227u) & XRT_RMASK]);
+                        }
+                        havail[hh] += chunk;
+                        again = again || (havail[hh] < XRT_AHEAD);
+                    }
+                }
+                __syncthreads();
+            }
         }
+        uint32_t hslot = 512u;      // slot of the current tile's first word, 0 or 512 (flipped when a tile starts)
+        uint32_t gstep = 3;         // chunks of the next tile's half that are generated (3 = all)
         KStream* st = args.streams + run;
         // the stream head: the run's own, or (SEG) the chunk head at or before this unit's first
         // Bragg uniform, which lies 2 * (candidates of the earlier segments) words into the draws
@@ -1014,24 +1041,21 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
         // must be separated by a barrier; they are placed in front of barriers
         // the tile needs anyway.
         auto mt_step = [&]() __attribute__((always_inline)) {
-            int h = 0;
+            if (gstep < 3u) {
+                const uint32_t cnt = gstep < 2u ? 171u : 170u;
+                if ((uint32_t)tid < cnt) {
+                    const uint32_t w = (hslot ^ 512u) + 171u * gstep + (uint32_t)tid;       // never wraps
+                    const uint32_t a = (w + 400u) & XRT_RMASK, c = (w + 797u) & XRT_RMASK;  // n - 624, n - 227
+                    const uint32_t b = (w + 401u) & XRT_RMASK;                              // n - 623
 #pragma unroll
-            for (int k = 0; k < 6; k++) {
-                if ((SRC.array_used >> k) & 1u) {
-                    uint32_t avail = hgen[k] - hpos[k];
-                    if (avail < XRT_AHEAD) {
-                        uint32_t chunk = XRT_AHEAD - avail;
-                        if (chunk > 227u) chunk = 227u;
-                        if ((uint32_t)tid < chunk) {
+                    for (int h = 0; h < 6; h++) {
+                        if (h < nh) {
                             uint32_t* r = rings + h * XRT_RING;
-                            uint32_t n = hgen[k] + (uint32_t)tid;
-                            r[n & XRT_RMASK] = mt_mix(r[(n - 624u) & XRT_RMASK], r[(n - 623u) & XRT_RMASK],
-                                                      r[(n - 227u) & XRT_RMASK]);
+                            r[w] = mt_mix(r[a], r[b], r[c]);
                         }
-                        hgen[k] += chunk;
                     }
-                    h++;
                 }
+                gstep++;
             }
             uint32_t avail = sgen - spos;
             if (avail < XRT_AHEAD) {
@@ -1044,13 +1068,6 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
                 }
                 sgen += chunk;
             }
-        };
-        auto heads_short = [&]() __attribute__((always_inline)) -> bool {
-            bool sh = false;
-#pragma unroll
-            for (int k = 0; k < 6; k++)
-                if ((SRC.array_used >> k) & 1u) sh = sh || ((hgen[k] - hpos[k]) < XRT_AHEAD);
-            return sh;
         };
 
         if (SEG) {
@@ -1218,23 +1235,24 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
 
             // everything this tile consumes must be generated: normally already
             // done behind the previous tile's barriers
-            while (heads_short()) { mt_step(); __syncthreads(); }
+            while (gstep < 3u) { mt_step(); __syncthreads(); }
+            hslot ^= 512u;
 
             double u[6];
             {
                 int h = 0;
+                const uint32_t pair = (hslot >> 1) + (uint32_t)tid;     // words hslot + 2 tid, + 1: one 8-byte read
 #pragma unroll
                 for (int k = 0; k < 6; k++) {
                     u[k] = 0.0;
                     if ((SRC.array_used >> k) & 1u) {
-                        const uint32_t* r = rings + h * XRT_RING;
-                        uint32_t n = hpos[k] + 2u * (uint32_t)tid;
-                        u[k] = mt_double(r[n & XRT_RMASK], r[(n + 1u) & XRT_RMASK]);
-                        hpos[k] += XRT_AHEAD;
+                        const uint2 w = reinterpret_cast<const uint2*>(rings + h * XRT_RING)[pair];
+                        u[k] = mt_double(w.x, w.y);
                         h++;
                     }
                 }
             }
+            gstep = 0;              // mt_step now fills the other half with the next tile's words
 
             Ray ray;
             V3 X;
