@@ -129,7 +129,9 @@ struct KOptic {
     const xrt_aperture_t* apertures;    // device
     const KMesh* mesh;                  // device (XRT_SHAPE_MESH)
     int32_t n_apertures;
-    int32_t pad;
+    int32_t scr_ok;                     // rocking-curve screen usable (one wavelength for all rays), see bragg_accept
+    double  scr_s, scr_a1, scr_a2, scr_a3;      // sin(bragg) and the series of asin(s + d) - asin(s) in d
+    double  scr_binv, scr_dmax, scr_ptail;      // 1 / (2 sigma^2), validity radius in d, bound on p outside it
 };
 
 struct KScene {
@@ -627,11 +629,38 @@ __device__ __forceinline__ double bragg_offset(const KOptic& op, const Ray& ray,
 __device__ __forceinline__ bool bragg_accept(const KOptic& op, const Ray& ray, const V3& nrm, double test,
                                              bool have_bragg, double bragg_shared)
 {
+    // |d . (-n)| == |d . n| bit for bit (negation commutes with every rounding), so the negated normal of
+    // the reference (:104) is not formed
+    double dt = fabs(dot_e(ray.d, nrm));
+    const double c = dt / norm3(ray.d);
+    // ---- screen -------------------------------------------------------------------------------------
+    // The decision is p >= test with p = R exp(-(inc - bragg)^2 / 2 sigma^2) (or the step function) and
+    // test a uniform deviate.  When every ray has the same wavelength, inc - bragg = asin(c) - asin(s) is a
+    // short series in d = c - s (constants from the host, relative error <= 1e-6 inside |d| < scr_dmax), and a
+    // single-precision exponential gives p to ~2e-5.  Unless `test` falls within 1e-3 (relative) of that
+    // estimate the outcome of the exact evaluation is already known; the exact evaluation below then only
+    // runs for about one candidate in a thousand (and for test == 0, NaNs, scenes without the screen).
+    if (op.scr_ok && have_bragg && test > 0.0) {
+        const double d = c - op.scr_s;
+        if (fabs(d) < op.scr_dmax) {
+            const double dfa = d * fma(d, fma(d, op.scr_a3, op.scr_a2), op.scr_a1);
+            if (op.rocking_type == XRT_ROCKING_STEP) {
+                const double a = fabs(dfa), m = fma(op.half_fwhm, 1e-6, 1e-12);
+                if (a < op.half_fwhm - m) return op.reflectivity >= test;       // p = 1.0 * R exactly
+                if (a > op.half_fwhm + m) return false;                         // p = 0.0 * R < test
+            } else {
+                const double xa = (dfa * dfa) * op.scr_binv;
+                const float xf = fminf((float)xa, 80.0f);
+                const double pa = (double)__builtin_amdgcn_exp2f(xf * -1.44269504f) * op.reflectivity;
+                if (test > pa * 1.001) return false;
+                if (xa < 80.0 && test < pa * 0.999) return true;
+            }
+        } else if (test > op.scr_ptail) return false;
+    }
+    // ---- exact evaluation, in the reference's order -----------------------------------------------------
     // a monochromatic source gives every ray the same asin argument: evaluated once per run
     double bragg = have_bragg ? bragg_shared : asin(ray.wl / op.two_d);
-    V3 neg; neg.x = -1.0 * nrm.x; neg.y = -1.0 * nrm.y; neg.z = -1.0 * nrm.z;
-    double dt = fabs(dot_e(ray.d, neg));
-    double inc = op.half_pi - acos(dt / norm3(ray.d));
+    double inc = op.half_pi - acos(c);
     double p;
     if (op.rocking_type == XRT_ROCKING_STEP) {
         p = (fabs(inc - bragg) <= op.half_fwhm) ? 1.0 : 0.0;
@@ -1750,6 +1779,52 @@ static bool needs_full(const xrt_scene_t* sc)
     return false;
 }
 
+// Constants of the rocking-curve screen in bragg_accept (not part of the reference's arithmetic: they only
+// decide which candidates need the exact evaluation).  Usable when all rays share one wavelength.
+static void bragg_screen(const xrt_source_t& src, KOptic& q)
+{
+    q.scr_ok = 0;
+    q.scr_s = q.scr_a1 = q.scr_a2 = q.scr_a3 = q.scr_binv = q.scr_dmax = 0.0;
+    q.scr_ptail = INFINITY;
+    if (q.interact != XRT_INTERACT_CRYSTAL || !(q.flags & XRT_F_CHECK_BRAGG)) return;
+    if (src.wavelength_dist != XRT_WL_CONST || src.has_velocity) return;
+    const double R = q.reflectivity;
+    if (!(R >= 0.0) || !std::isfinite(R)) return;
+    const double s0 = (1.0 * src.wavelength) / q.two_d;
+    if (!(fabs(s0) < 0.995)) return;
+    const double u = 1.0 - s0 * s0;
+    const double a1 = 1.0 / sqrt(u), a2 = s0 / (2.0 * u * sqrt(u)), a3 = (1.0 + 2.0 * s0 * s0) / (6.0 * u * u * sqrt(u));
+    auto rel_err = [&](double d) {
+        const double exact = asin(s0 + d) - asin(s0), ser = d * (a1 + d * (a2 + d * a3));
+        return fabs(ser - exact) / fabs(exact);
+    };
+    double dmax = 0.05 * u;
+    for (int it = 0; it < 200; it++) {
+        double worst = 0.0;
+        for (int j = 4; j <= 8; j++) {
+            const double d = dmax * j / 8.0;
+            if (fabs(s0 + d) >= 1.0 || fabs(s0 - d) >= 1.0) { worst = 1.0; break; }
+            const double e1 = rel_err(d), e2 = rel_err(-d);
+            if (e1 > worst) worst = e1;
+            if (e2 > worst) worst = e2;
+        }
+        if (worst <= 1e-6) break;
+        dmax *= 0.8;
+        if (it == 199) return;
+    }
+    if (q.rocking_type == XRT_ROCKING_STEP) {
+        if (!(q.half_fwhm >= 0.0) || !std::isfinite(q.half_fwhm)) return;
+        // outside the radius |inc - bragg| >= |d| >= dmax: p = 0 when that is beyond the half width
+        q.scr_ptail = (dmax > q.half_fwhm * (1.0 + 1e-6) + 1e-12) ? 0.0 : INFINITY;
+    } else {
+        if (!(q.two_sigma2 > 0.0) || !std::isfinite(q.two_sigma2)) return;
+        q.scr_binv = 1.0 / q.two_sigma2;
+        if (dmax * dmax * q.scr_binv >= 46.0) q.scr_ptail = R * exp(-45.0) * 1.001;
+    }
+    q.scr_s = s0; q.scr_a1 = a1; q.scr_a2 = a2; q.scr_a3 = a3; q.scr_dmax = dmax;
+    q.scr_ok = 1;
+}
+
 static void build_kscene(const xrt_scene_t* sc, char* ws, KScene* k)
 {
     memset(k, 0, sizeof(*k));
@@ -1817,6 +1892,7 @@ static void build_kscene(const xrt_scene_t* sc, char* ws, KScene* k)
         q.pixel_nx = o.pixel_nx; q.pixel_ny = o.pixel_ny; q.image_offset = o.image_offset;
         q.n_apertures = o.n_apertures;
         q.apertures = reinterpret_cast<const xrt_aperture_t*>(ws + ws_off_apertures()) + (size_t)e * XRT_MAX_APERTURES;
+        bragg_screen(s, q);
     }
 }
 
