@@ -218,7 +218,25 @@ struct V3 { double x, y, z; };
 __device__ __forceinline__ double dot_e(const V3& a, const V3& b) { return (a.x * b.x + a.z * b.z) + a.y * b.y; }
 __device__ __forceinline__ double dot_n(const V3& a, const V3& b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 __device__ __forceinline__ double dot_blas(const V3& a, const V3& b) { return fma(a.z, b.z, fma(a.x, b.x, a.y * b.y)); }
-__device__ __forceinline__ double norm3(const V3& a) { return sqrt(dot_n(a, a)); }
+// Correctly rounded square root.  The library routine first rescales arguments below 2^-767 and picks the
+// argument itself for 0 / inf at the end (eight instructions that never act on lengths and discriminants of
+// order one); arguments outside [2^-700, 2^700], negative ones and NaN take the library path, the others the
+// same v_rsq_f64 + refinement steps without the rescaling.
+__device__ __forceinline__ double sqrt_rn(double x)
+{
+    const uint32_t hi = (uint32_t)__double2hiint(x);
+    if (!(hi - 0x14300000u < 0x57800000u)) return sqrt(x);      // exponent field in [0x143, 0x6bb), sign clear
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = y * 0.5;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    double d = fma(-g, g, x);
+    g = fma(d, h, g);
+    d = fma(-g, g, x);
+    return fma(d, h, g);
+}
+__device__ __forceinline__ double norm3(const V3& a) { return sqrt_rn(dot_n(a, a)); }
 __device__ __forceinline__ V3 cross3(const V3& a, const V3& b)
 {
     V3 c;
@@ -320,16 +338,24 @@ struct Ray {
 };
 
 // u[k] = the k-th array's double for this ray (0.0 for arrays whose value cannot matter)
-template <bool FULL>
-__device__ __forceinline__ void source_ray(const KSource& s, const double* u, Ray& ray)
+// generate_origin (:229-255): origin + x*xaxis + y*yaxis + z*zaxis, left to right
+__device__ __forceinline__ V3 source_origin(const KSource& s, double u0, double u1, double u2)
 {
-    // generate_origin (:229-255): origin + x*xaxis + y*yaxis + z*zaxis, left to right
-    double xo = s.low[0] + s.range[0] * u[0];
-    double yo = s.low[1] + s.range[1] * u[1];
-    double zo = s.low[2] + s.range[2] * u[2];
-    ray.o.x = ((s.origin[0] + xo * s.xaxis[0]) + yo * s.yaxis[0]) + zo * s.zaxis[0];
-    ray.o.y = ((s.origin[1] + xo * s.xaxis[1]) + yo * s.yaxis[1]) + zo * s.zaxis[1];
-    ray.o.z = ((s.origin[2] + xo * s.xaxis[2]) + yo * s.yaxis[2]) + zo * s.zaxis[2];
+    V3 o;
+    double xo = s.low[0] + s.range[0] * u0;
+    double yo = s.low[1] + s.range[1] * u1;
+    double zo = s.low[2] + s.range[2] * u2;
+    o.x = ((s.origin[0] + xo * s.xaxis[0]) + yo * s.yaxis[0]) + zo * s.zaxis[0];
+    o.y = ((s.origin[1] + xo * s.xaxis[1]) + yo * s.yaxis[1]) + zo * s.zaxis[1];
+    o.z = ((s.origin[2] + xo * s.xaxis[2]) + yo * s.yaxis[2]) + zo * s.zaxis[2];
+    return o;
+}
+
+// `have_origin`: ray.o is already set (a point source: one origin per run)
+template <bool FULL>
+__device__ __forceinline__ void source_ray(const KSource& s, const double* u, Ray& ray, bool have_origin = false)
+{
+    if (!have_origin) ray.o = source_origin(s, u[0], u[1], u[2]);
 
     // make_normal + basis (:262-285; Directed :46-50; Focused :40-44)
     V3 n, o1, o2;
@@ -353,7 +379,7 @@ __device__ __forceinline__ void source_ray(const KSource& s, const double* u, Ra
     if (!FULL || s.angular_dist == XRT_ANG_ISOTROPIC) {
         double z = s.ang[0] + (1.0 - s.ang[0]) * u[3];
         double phi = 0.0 + (s.two_pi - 0.0) * u[4];
-        double st = sqrt(1.0 - z * z);
+        double st = sqrt_rn(1.0 - z * z);
         double sn, cs;
         sincos_0_2pi(phi, &sn, &cs);
         l0 = st * cs; l1 = st * sn; l2 = z;
@@ -457,8 +483,21 @@ __device__ double quartic_root(double b0, double c0, double d0, double e0, int w
 
 // Shape*.intersect_distance + location_from_distance: the intersection point.
 // Returns false when the ray has no intersection (mask &= ... in the reference).
+// What a point source's first element needs of the (single) ray origin, evaluated once per run with the
+// same operations the per-ray code uses: sphere: L = centre - O and L.L; plane: (origin - O) . zaxis.
+struct PointPre { V3 L; double LL, num; };
+
+__device__ __forceinline__ PointPre point_pre(const KOptic& op, const V3& O)
+{
+    PointPre p;
+    p.L = sub3(ld3(op.center), O);
+    p.LL = dot_e(p.L, p.L);
+    p.num = dot_blas(sub3(ld3(op.origin), O), ld3(op.R + 6));
+    return p;
+}
+
 template <bool FULL>
-__device__ __forceinline__ bool intersect_point(const KOptic& op, const Ray& ray, V3& X)
+__device__ __forceinline__ bool intersect_point(const KOptic& op, const Ray& ray, V3& X, bool pre, const PointPre& pp)
 {
     double t;
     if (op.shape == XRT_SHAPE_PLANE) {
@@ -469,17 +508,17 @@ __device__ __forceinline__ bool intersect_point(const KOptic& op, const Ray& ray
             t = dot_blas(v, ez) / dot_blas(ray.d, ez);
         } else {
             V3 za = ld3(op.R + 6);
-            V3 v = sub3(ld3(op.origin), ray.o);
-            t = dot_blas(v, za) / dot_blas(ray.d, za);
+            const double num = pre ? pp.num : dot_blas(sub3(ld3(op.origin), ray.o), za);
+            t = num / dot_blas(ray.d, za);
         }
         if (!(t >= 0.0)) return false;
     } else if (!FULL || op.shape == XRT_SHAPE_SPHERE) {
         // optics/_ShapeSphere.py:52-100
-        V3 L = sub3(ld3(op.center), ray.o);
+        V3 L = pre ? pp.L : sub3(ld3(op.center), ray.o);
         double t_ca = dot_e(L, ray.d);
-        double dd = sqrt(dot_e(L, L) - t_ca * t_ca);
+        double dd = sqrt_rn((pre ? pp.LL : dot_e(L, L)) - t_ca * t_ca);
         if (!(dd <= op.radius)) return false;
-        double t_hc = sqrt(op.radius2 - dd * dd);
+        double t_hc = sqrt_rn(op.radius2 - dd * dd);
         double t0 = t_ca - t_hc, t1 = t_ca + t_hc;
         if (op.flags & XRT_F_CONVEX) t = (t0 < t1) ? t0 : t1;
         else                         t = (t0 > t1) ? t0 : t1;
@@ -1001,7 +1040,7 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
                     uint32_t* r = rings + h * XRT_RING;
                     const uint32_t nx = uni32((uint32_t)src->next), gn = uni32((uint32_t)src->gen);
                     for (int i = tid; i < (int)XRT_RING; i += XRT_TILE) r[((uint32_t)i - nx) & XRT_RMASK] = src->ring[i];
-                    havail[h] = gn - nx;
+                    havail[k] = gn - nx;
                     h++;
                 }
             }
@@ -1012,19 +1051,21 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
             bool again = true;
             while (again) {
                 again = false;
+                int hh = 0;
 #pragma unroll
-                for (int hh = 0; hh < 6; hh++) {
-                    if (hh < nh && havail[hh] < XRT_AHEAD) {
-                        uint32_t chunk = XRT_AHEAD - havail[hh];
+                for (int k = 0; k < 6; k++) {           // (array k <-> ring hh; unused arrays keep havail = XRT_AHEAD)
+                    if (havail[k] < XRT_AHEAD) {
+                        uint32_t chunk = XRT_AHEAD - havail[k];
                         if (chunk > 227u) chunk = 227u;
                         if ((uint32_t)tid < chunk) {
                             uint32_t* r = rings + hh * XRT_RING;
-                            const uint32_t n = havail[hh] + (uint32_t)tid;
+                            const uint32_t n = havail[k] + (uint32_t)tid;
                             r[n & XRT_RMASK] = mt_mix(r[(n - 624u) & XRT_RMASK], r[(n - 623u) & XRT_RMASK], r[(n - 227u) & XRT_RMASK]);
                         }
-                        havail[hh] += chunk;
-                        again = again || (havail[hh] < XRT_AHEAD);
+                        havail[k] += chunk;
+                        again = again || (havail[k] < XRT_AHEAD);
                     }
+                    if ((SRC.array_used >> k) & 1u) hh++;
                 }
                 __syncthreads();
             }
@@ -1108,6 +1149,18 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
             }
         }
 
+        // A point source (no spatial array in use: every offset is -0 + 0 u = 0) has one origin per run;
+        // it and what the first element derives from it alone are evaluated here instead of per ray
+        const bool point = !EXT && (SRC.array_used & 7u) == 0u && SRC.kind != XRT_SRC_FOCUSED && SC.n_optics > 0;
+        V3 O_run;
+        PointPre pre0;
+        O_run.x = O_run.y = O_run.z = 0.0;
+        pre0.L = O_run; pre0.LL = 0.0; pre0.num = 0.0;
+        if (point) {
+            O_run = source_origin(SRC, 0.0, 0.0, 0.0);
+            pre0 = point_pre(SC.opt[0], O_run);
+        }
+
         // Bragg angle shared by all rays when the wavelength is one constant
         const bool wl_shared = (SRC.wavelength_dist == XRT_WL_CONST) && !SRC.has_velocity;
         double bragg_shared = 0.0;
@@ -1140,7 +1193,7 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
                             if (is_mesh) {
                                 const MeshHit h = mesh_hit(op.mesh, ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z);
                                 hit = h.hit != 0; X.x = h.x; X.y = h.y; X.z = h.z; aux = h.aux;
-                            } else hit = intersect_point<FULL>(op, ray, X);
+                            } else hit = intersect_point<FULL>(op, ray, X, false, pre0);
                             alive = hit && check_bounds<FULL>(op, X);
                             if (HIST && !alive && !counting) {
                                 V3 xo = X, dd = ray.d;
@@ -1172,7 +1225,8 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
                         }
                     } else {
                         if (have) {
-                            bool hit = intersect_point<FULL>(op, ray, X);
+                            // (e == 0 is only ever reached with rays straight from the source)
+                            bool hit = intersect_point<FULL>(op, ray, X, point && e == 0, pre0);
                             alive = hit && check_bounds<FULL>(op, X);
                             if (HIST && !alive && !counting) {
                                 V3 xo = X;
@@ -1296,7 +1350,8 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
             have = have && (u[3] + u[4] < -1.0);
             if (have)
 #endif
-            source_ray<FULL>(SRC, u, ray);
+            if (point) ray.o = O_run;
+            source_ray<FULL>(SRC, u, ray, point);
 #if XRT_ABLATE == 3
             have = have && (id == 0xffffffffu);
 #endif
