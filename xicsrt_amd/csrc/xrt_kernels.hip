@@ -46,7 +46,10 @@
 #define XRT_AHEAD    512u       // words every head keeps generated ahead of its read position
 #define XRT_STRETCH  20560      // 19937 + 623 words: what one jump reads
 #define XRT_TILE_COMP 7         // x,y,z, dx,dy,dz, wavelength
-#define XRT_QCAP     448u       // records in the fused kernel's circular ray buffer (63 survivors + 127 queued + 256 new)
+// Records of the fused kernel's circular ray buffer: 63 survivors + (batch - 1) queued candidates + 256 new
+// ones, for Bragg batches of 128 or 256 candidates (the host takes 256 when that costs no workgroup per CU)
+#define XRT_QCAP_128 448u
+#define XRT_QCAP_256 576u
 
 // --------------------------------------------------------------------------
 // kernel-argument scene (passed by value: uniform, read through scalar loads)
@@ -923,6 +926,8 @@ struct KArgs {
     // the words the rejection sampler consumed in front of the Bragg uniforms (null: none)
     const double*   wl_array;           // [n_runs][n_rays]
     const uint64_t* base_words;         // [n_runs]
+    // circular ray buffer in LDS: capacity in records and the Bragg batch (128 or 256 candidates)
+    uint32_t qcap, bragg_batch;
 };
 
 #ifndef XRT_WAVES_PER_EU
@@ -968,10 +973,15 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
     //  (a) the FIFO queue of rays waiting for the Bragg test (filled tile by tile in ray
     //      order, drained 128 at a time so that the test always runs on two full waves), and
     //  (b) scratch for the stable compactions between the other elements (its free part).
-    double*   qbuf   = reinterpret_cast<double*>(lds_raw);                             // [7][XRT_QCAP]
-    uint32_t* qid    = reinterpret_cast<uint32_t*>(qbuf + XRT_TILE_COMP * XRT_QCAP);   // [XRT_QCAP]
-    uint32_t* qaux   = qid + XRT_QCAP;                                                 // [XRT_QCAP] (EXT only)
-    uint32_t* rings  = qaux + (EXT ? XRT_QCAP : 0u);                                   // [nh+1][1024]
+    // A record is the point (3), the direction (3), the wavelength unless all rays share one, and (HIST) the
+    // ray index; a mesh / local-frame variant also keeps the hit face.
+    const KScene* scl0 = scene_fresh(scene_g);
+    const bool q_has_wl = !(scl0->src.wavelength_dist == XRT_WL_CONST && !scl0->src.has_velocity);
+    const uint32_t qcap = args.qcap, bbatch = args.bragg_batch;
+    double*   qbuf   = reinterpret_cast<double*>(lds_raw);                             // [6 or 7][qcap]
+    uint32_t* qid    = reinterpret_cast<uint32_t*>(qbuf + (q_has_wl ? 7u : 6u) * qcap); // [qcap] (HIST only)
+    uint32_t* qaux   = qid + (HIST ? qcap : 0u);                                       // [qcap] (EXT only)
+    uint32_t* rings  = qaux + (EXT ? qcap : 0u);                                       // [nh+1][1024]
     const int tid = threadIdx.x;
     const KScene* scl = scene_fresh(scene_g);
     const int64_t N = SRC.n_rays;
@@ -995,19 +1005,20 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
     for (int e = 0; e < SC.n_optics; e++)
         if (SC.opt[e].interact == XRT_INTERACT_CRYSTAL && (SC.opt[e].flags & XRT_F_CHECK_BRAGG)) be = e;
 
+    double wl_run = 0.0;        // the wavelength of every ray when it is not part of the records
     auto q_store = [&](uint32_t i, const V3& o, const V3& d, double wl, uint32_t id) __attribute__((always_inline)) {
-        qbuf[0 * XRT_QCAP + i] = o.x; qbuf[1 * XRT_QCAP + i] = o.y; qbuf[2 * XRT_QCAP + i] = o.z;
-        qbuf[3 * XRT_QCAP + i] = d.x; qbuf[4 * XRT_QCAP + i] = d.y; qbuf[5 * XRT_QCAP + i] = d.z;
-        qbuf[6 * XRT_QCAP + i] = wl;
-        qid[i] = id;
+        qbuf[0 * qcap + i] = o.x; qbuf[1 * qcap + i] = o.y; qbuf[2 * qcap + i] = o.z;
+        qbuf[3 * qcap + i] = d.x; qbuf[4 * qcap + i] = d.y; qbuf[5 * qcap + i] = d.z;
+        if (q_has_wl) qbuf[6 * qcap + i] = wl;
+        if (HIST) qid[i] = id;
     };
     auto q_load = [&](uint32_t i, V3& o, V3& d, double& wl, uint32_t& id) __attribute__((always_inline)) {
-        o.x = qbuf[0 * XRT_QCAP + i]; o.y = qbuf[1 * XRT_QCAP + i]; o.z = qbuf[2 * XRT_QCAP + i];
-        d.x = qbuf[3 * XRT_QCAP + i]; d.y = qbuf[4 * XRT_QCAP + i]; d.z = qbuf[5 * XRT_QCAP + i];
-        wl = qbuf[6 * XRT_QCAP + i];
-        id = qid[i];
+        o.x = qbuf[0 * qcap + i]; o.y = qbuf[1 * qcap + i]; o.z = qbuf[2 * qcap + i];
+        d.x = qbuf[3 * qcap + i]; d.y = qbuf[4 * qcap + i]; d.z = qbuf[5 * qcap + i];
+        wl = q_has_wl ? qbuf[6 * qcap + i] : wl_run;
+        id = HIST ? qid[i] : 0u;
     };
-    auto q_wrap = [](uint32_t i) -> uint32_t { return i >= XRT_QCAP ? i - XRT_QCAP : i; };
+    auto q_wrap = [&](uint32_t i) __attribute__((always_inline)) -> uint32_t { return i >= qcap ? i - qcap : i; };
 
     for (;;) {
         // ---- next run ------------------------------------------------------
@@ -1165,6 +1176,7 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
         const bool wl_shared = (SRC.wavelength_dist == XRT_WL_CONST) && !SRC.has_velocity;
         double bragg_shared = 0.0;
         if (wl_shared && be >= 0) bragg_shared = asin((1.0 * SRC.wavelength) / SC.opt[be].two_d);
+        wl_run = 1.0 * SRC.wavelength;
 
         // Elements without a Bragg test, starting at element `e` with rays held by the threads
         // tid < n_in (`fresh` = the rays still have to be intersected with element e; otherwise
@@ -1301,7 +1313,7 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
                 Xb.x = Xb.y = Xb.z = 0.0;
                 rb.o = Xb; rb.d = Xb; rb.wl = 0.0;
                 if (have_b) {
-                    q_load(q_wrap(qhead + XRT_QCAP - bcount + vt), rb.o, rb.d, rb.wl, idb);
+                    q_load(q_wrap(qhead + qcap - bcount + vt), rb.o, rb.d, rb.wl, idb);
                     if ((opb.flags & XRT_F_IMAGE) && args.images) image_hit(opb, rb.o, args.images);
                 }
                 bcount -= n;
@@ -1394,17 +1406,16 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
                 qcount += n_a;
             }
 
-            // ---- Bragg test + the remaining elements, 128 queued rays at a time -----------
+            // ---- Bragg test, a batch (128 or 256) of queued rays at a time ------------------
             const bool last_tile = (i0 + XRT_TILE >= ray_hi);
-            while (be >= 0 && (qcount >= 128u || (last_tile && qcount > 0u))) {
+            while (be >= 0 && (qcount >= bbatch || (last_tile && qcount > 0u))) {
                 scl = scene_fresh(scene_g);
                 const KOptic& op = SC.opt[be];
-                const uint32_t nb = qcount < 128u ? qcount : 128u;
+                const uint32_t nb = qcount < bbatch ? qcount : bbatch;
                 // n uniforms from the stream head (np.random.uniform(0,1,n_live), optics/_InteractCrystal.py:189)
                 while ((sgen - spos) < 2u * nb) { mt_step(); __syncthreads(); }
                 mt_step();
                 __syncthreads();                                  // queue records visible
-                rotw = (rotw + 1u) & 3u;                          // this batch: virtual waves 0,1 = hardware waves -rotw, 1-rotw
                 const uint32_t vt = vtid();
                 have = vt < nb;
                 alive = false;
@@ -1477,15 +1488,15 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
                 uint32_t mid = 0;
                 mo.x = mo.y = mo.z = 0.0; md = mo;
                 const bool mover = (vt >= 192u) && (vt - 192u < bcount);
-                if (mover) q_load(q_wrap(head_old + XRT_QCAP - bcount + (vt - 192u)), mo, md, mwl, mid);
+                if (mover) q_load(q_wrap(head_old + qcap - bcount + (vt - 192u)), mo, md, mwl, mid);
                 uint32_t n_s;
                 mt_step();
                 const uint32_t srank = wg_rank(alive, wave_tot, slot, tid, n_s, rotw);
                 if (tid == 0) cnt[be + 1] += n_s;
-                if (alive) q_store(q_wrap(qhead + XRT_QCAP - n_s + srank), ray.o, ray.d, ray.wl, id);
-                if (mover && n_s < nb) q_store(q_wrap(qhead + XRT_QCAP - n_s - bcount + (vt - 192u)), mo, md, mwl, mid);
+                if (alive) q_store(q_wrap(qhead + qcap - n_s + srank), ray.o, ray.d, ray.wl, id);
+                if (mover && n_s < nb) q_store(q_wrap(qhead + qcap - n_s - bcount + (vt - 192u)), mo, md, mwl, mid);
                 bcount += n_s;
-                rotw = (rotw + 2u) & 3u;
+                rotw = (rotw + ((nb + 63u) >> 6)) & 3u;
                 // ---- survivors: 64 at a time (everything that is left behind the run's last batch) through
                 // the elements behind the Bragg element, on one full wave
                 drain_survivors(last_tile && qcount == 0u);
@@ -1951,12 +1962,29 @@ static void build_kscene(const xrt_scene_t* sc, char* ws, KScene* k)
     }
 }
 
-static size_t lds_bytes(int n_src_heads, bool ext)
+static size_t lds_bytes(int n_src_heads, bool ext, bool hist, bool has_wl, uint32_t qcap)
 {
-    size_t b = sizeof(double) * XRT_TILE_COMP * XRT_QCAP + sizeof(uint32_t) * XRT_QCAP * (ext ? 2 : 1);
+    size_t b = sizeof(double) * (has_wl ? 7 : 6) * qcap + sizeof(uint32_t) * qcap * ((ext ? 1 : 0) + (hist ? 1 : 0));
     b += sizeof(uint32_t) * XRT_RING * (size_t)(n_src_heads + 1);
     b += sizeof(uint32_t) * (8 + 2 * (XRT_DEV_MAX_OPTICS + 2) + 8);
     return (b + 15) & ~(size_t)15;
+}
+// Bragg batches of 256 candidates (all four waves busy, half as many batches) when the larger ray buffer
+// does not cost a workgroup per CU (160 KiB of LDS), else 128
+static size_t plan_queue(const KScene& ks, int n_src_heads, bool ext, bool hist, KArgs* a)
+{
+    const bool has_wl = !(ks.src.wavelength_dist == XRT_WL_CONST && !ks.src.has_velocity);
+    const size_t l128 = lds_bytes(n_src_heads, ext, hist, has_wl, XRT_QCAP_128);
+    const size_t l256 = lds_bytes(n_src_heads, ext, hist, has_wl, XRT_QCAP_256);
+    const size_t cu = 160u * 1024u;
+    size_t w128 = cu / l128, w256 = cu / l256;
+    const size_t wmax = ext ? 2 : 4;            // what the register budget of the variant allows anyway
+    if (w128 > wmax) w128 = wmax;
+    if (w256 > wmax) w256 = wmax;
+    const bool big = w256 >= w128 && w256 >= 1 && !getenv("XICSRT_BRAGG_BATCH_128");
+    a->qcap = big ? XRT_QCAP_256 : XRT_QCAP_128;
+    a->bragg_batch = big ? 256u : 128u;
+    return big ? l256 : l128;
 }
 
 // device copy of every mesh's tables behind the staged region; fills KOptic.mesh
@@ -2367,7 +2395,7 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
         }
         int variant = needs_ext(sc) ? 2 : (needs_full(sc) ? 1 : 0);
         if (variant == 0 && n_gch > 0) variant = 3;         // lean geometry, wavelength per ray from the prepared array
-        const size_t lds = lds_bytes(nh, variant == 2);
+        const size_t lds = plan_queue(ks, nh, variant == 2, hist, &a);
         // (a run that is one segment has nothing in front of it: no count pass)
         for (int mode = ((be >= 0 && S > 1) ? 1 : 2); mode <= 2; mode++) {
             a.mode = mode;
@@ -2418,7 +2446,7 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
     a.run_counter = reinterpret_cast<uint32_t*>(ws);
     HIP_TRY(hipMemsetAsync(ws, 0, 64, stream));
     const int variant = needs_ext(sc) ? 2 : (needs_full(sc) ? 1 : 0);
-    const size_t lds = lds_bytes(nh, variant == 2);
+    const size_t lds = plan_queue(ks, nh, variant == 2, hist, &a);
     if (hist) {
         if (variant == 2) return launch_variant<true, 2>(device_scene(ws), a, n_runs, lds, stream);
         return variant == 1 ? launch_variant<true, 1>(device_scene(ws), a, n_runs, lds, stream) : launch_variant<true, 0>(device_scene(ws), a, n_runs, lds, stream);
