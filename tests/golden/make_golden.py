@@ -408,6 +408,53 @@ def build_cases():
                      **dict(_BRAGG, check_bragg=False))
         tag = 'interp' if interp else 'flat'
         add('E_mesh_%s_trace' % tag, 'trace', cfg_three(500, c, history=True, seed=71))
+    # --- ten optics in a row (more than the eight the first device path could take): five apertures between
+    #     the source and the crystal, the Bragg crystal, three apertures on the reflected beam, the detector
+    cfg = cfg_three(4000, dict(sph, rocking_fwhm=2e-3), history=True, seed=55)
+    crystal_at = np.array([0.0, 0.0, 0.80374151])
+    det_at = np.array([0.0, 0.76871290, 0.56904832])
+    out_dir = (det_at - crystal_at) / np.linalg.norm(det_at - crystal_at)
+    optics = {}
+    shapes = [{'shape': 'circle', 'size': [0.016]}, {'shape': 'square', 'size': [0.058]},
+              {'shape': 'rectangle', 'size': [0.10, 0.085]}, {'shape': 'ellipse', 'size': [0.068, 0.06]},
+              {'shape': 'circle', 'size': [0.078]}]
+    for i, ap in enumerate(shapes):
+        z = 0.1 * (i + 1)
+        optics['ap%d' % i] = {'class_name': 'XicsrtOpticAperture', 'origin': [0.0, 0.0, z], 'zaxis': [0.0, 0.0, -1.0],
+                              'xsize': 0.3, 'ysize': 0.3, 'aperture': [ap]}
+    optics['crystal'] = cfg['optics']['crystal']
+    for i, f in enumerate((0.25, 0.5, 0.75)):
+        optics['out%d' % i] = {'class_name': 'XicsrtOpticAperture', 'origin': (crystal_at + f * (det_at - crystal_at)).tolist(),
+                               'zaxis': (-out_dir).tolist(), 'xsize': 0.5, 'ysize': 0.5,
+                               'aperture': [{'shape': 'circle', 'size': [0.045 - 0.008 * i]}]}
+    optics['detector'] = cfg['optics']['detector']
+    cfg['optics'] = optics
+    add('Q_ten_trace', 'trace', cfg)
+    cfg2 = copy.deepcopy(cfg)
+    cfg2['general'].update(keep_history=False, number_of_iter=2, number_of_runs=3)
+    cfg2['sources']['source']['intensity'] = 60000
+    add('Q_ten_counts', 'counts', cfg2)
+
+    # --- BASELINE.json configurations at their stated geometry, reference-sized run counts -----------------
+    # cfg2: point source -> planar mirror -> detector, 1e6 rays per run
+    add('B_cfg2_mirror_1e6', 'counts', cfg_three(1000000, mir, seed=81, runs=2))
+    # cfg3: directed source -> spherical Bragg crystal -> detector, 1e6 rays per run
+    add('C_cfg3_sphere_1e6', 'counts', cfg_three(1000000, sph, seed=82, runs=2))
+    # cfg4: W7-X style plasma volume (2000 bundles per run, Poisson statistics, 1 keV) -> spherical crystal ->
+    #       2D detector with 0.5 mm pixels (800 x 400 bins)
+    p4 = {'class_name': 'XicsrtPlasmaCubic', 'origin': [0.0, 0.0, 0.0],
+          'xsize': 0.1, 'ysize': 0.1, 'zsize': 0.1,
+          'target': [0.0, 0.0, 0.80374151], 'emissivity': 2e15, 'time_resolution': 1e-3,
+          'temperature': 1000.0, 'mass_number': 39.948, 'linewidth': 0.0,
+          'wavelength': 3.9492, 'spread': float(np.radians(1.0)), 'use_poisson': True,
+          'bundle_count': 2000, 'bundle_volume': 0.001 / 2000, 'bundle_type': 'voxel'}
+    add('F_cfg4_plasma_counts', 'counts', cfg_three(0, sph, source=p4, detector=_detector(pixel_size=5e-4),
+                                                    seed=83, runs=3))
+    # cfg5: toroidal mesh crystal 41 x 41 (interpolated and flat), rocking-curve test on
+    for interp in (False, True):
+        c = _crystal('XicsrtOpticMeshToroidalCrystal', radius_major=1.0, radius_minor=0.2,
+                     mesh_size=[41, 41], mesh_interpolate=interp, **_BRAGG)
+        add('E_cfg5_mesh_%s_1e5' % ('interp' if interp else 'flat'), 'counts', cfg_three(100000, c, seed=84, runs=2))
     return C
 
 

@@ -38,7 +38,7 @@
 
 #include "../../include/xicsrt_hip.h"
 
-#define XRT_DEV_MAX_OPTICS 8
+#define XRT_DEV_MAX_OPTICS XRT_MAX_OPTICS      // (16) the scene lives in device memory: no kernel-argument limit
 #define XRT_TILE     256
 #define XRT_RING     1024u
 #define XRT_RMASK    1023u
@@ -1592,7 +1592,7 @@ extern "C" int xrt_scene_check(const xrt_scene_t* sc)
             return fail(-3, "%s", "a temperature profile with a natural linewidth is not implemented on the device path");
     }
     if (sc->n_optics < 0 || sc->n_optics > XRT_DEV_MAX_OPTICS)
-        return fail(-2, "%s", "device path supports at most 8 optics");
+        return fail(-2, "%s", "device path supports at most 16 optics (XRT_MAX_OPTICS)");
     const xrt_source_t& s = sc->source;
     if (s.intensity < 0) return fail(-2, "%s", "negative intensity");
     if (s.spatial_dist != XRT_SPATIAL_UNIFORM && s.spatial_dist != XRT_SPATIAL_GAUSSIAN)
@@ -2253,9 +2253,9 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
         if (src != 2 && !hist && !no_split) {
             // source and optics in separate launches, a batch of `slots` runs at a time
             g.n_src_slot = reinterpret_cast<int64_t*>(g.bundle_off + (size_t)slots * XRT_ST_BUNDLE_ROWS * (size_t)(sc->source.bundle_count > 0 ? sc->source.bundle_count : 0));
-            void (*k1)(const KScene, const KArgs, const KStaged) = src == 1 ? xrt_staged_kernel<false, 1, false, 1>
+            void (*k1)(const KScene*, const KArgs, const KStaged) = src == 1 ? xrt_staged_kernel<false, 1, false, 1>
                                                                             : xrt_staged_kernel<false, 0, false, 1>;
-            void (*k2)(const KScene, const KArgs, const KStaged) =
+            void (*k2)(const KScene*, const KArgs, const KStaged) =
                 src == 1 ? (special ? xrt_staged_kernel<false, 1, true, 2> : xrt_staged_kernel<false, 1, false, 2>)
                          : (special ? xrt_staged_kernel<false, 0, true, 2> : xrt_staged_kernel<false, 0, false, 2>);
             for (int base_run = 0; base_run < n_runs; base_run += slots) {
@@ -2265,22 +2265,22 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
                 const int g1 = src == 1 ? 768 : 1024, g2 = special ? 512 : 768;     // workgroups per launch: 3-4 (source) and 3 or 1 (optics) per CU
                 int grid1 = nb < g1 ? nb : g1, grid2 = nb < g2 ? nb : g2;
                 HIP_TRY(hipMemsetAsync(ws, 0, 64, stream));
-                hipLaunchKernelGGL(k1, dim3(grid1), dim3(XRT_TILE), lds, stream, ks, a, g);
+                hipLaunchKernelGGL(k1, dim3(grid1), dim3(XRT_TILE), lds, stream, device_scene(ws), a, g);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipMemsetAsync(ws, 0, 64, stream));
-                hipLaunchKernelGGL(k2, dim3(grid2), dim3(XRT_TILE), lds, stream, ks, a, g);
+                hipLaunchKernelGGL(k2, dim3(grid2), dim3(XRT_TILE), lds, stream, device_scene(ws), a, g);
                 HIP_TRY(hipGetLastError());
             }
             if (ti >= 0) HIP_TRY(hipEventRecord(timing_ev[ti][1], stream));
             return 0;
         }
-        void (*kern)(const KScene, const KArgs, const KStaged);
+        void (*kern)(const KScene*, const KArgs, const KStaged);
         if (hist) kern = src == 2 ? (special ? xrt_staged_kernel<true, 2, true> : xrt_staged_kernel<true, 2, false>)
                        : src == 1 ? (special ? xrt_staged_kernel<true, 1, true> : xrt_staged_kernel<true, 1, false>)
                                   : (special ? xrt_staged_kernel<true, 0, true> : xrt_staged_kernel<true, 0, false>);
         else      kern = src == 1 ? (special ? xrt_staged_kernel<false, 1, true> : xrt_staged_kernel<false, 1, false>)
                                   : (special ? xrt_staged_kernel<false, 0, true> : xrt_staged_kernel<false, 0, false>);
-        hipLaunchKernelGGL(kern, dim3(slots), dim3(XRT_TILE), lds, stream, ks, a, g);
+        hipLaunchKernelGGL(kern, dim3(slots), dim3(XRT_TILE), lds, stream, device_scene(ws), a, g);
         HIP_TRY(hipGetLastError());
         if (ti >= 0) HIP_TRY(hipEventRecord(timing_ev[ti][1], stream));
         return 0;
