@@ -72,16 +72,41 @@ class ConfigObject:
         _config.update_config(self.config, config_new, **kwargs)
 
 
+# ---------------------------------------------------------------------------
+# frames
+# ---------------------------------------------------------------------------
+# The numbers below feed the device (scene.py copies `origin` and `orientation` into the C structs), so the
+# operations are the ones the reference's objects perform (xicsrt/objects/_GeometryObject.py:76-111): the
+# frame's rows are x, z cross x, z; nothing is re-orthonormalised and zaxis is taken as given.
+
+_UP = (0.0, 0.0, 1.0)
+
+
+def default_xaxis(zaxis):
+    """x axis of an element that names none: the horizontal direction perpendicular to zaxis."""
+    sideways = np.cross(np.array(_UP), zaxis)
+    if np.any(sideways != 0.0):
+        return sideways / np.linalg.norm(sideways)
+    return np.array([1.0, 0.0, 0.0])            # zaxis is vertical: any horizontal axis will do
+
+
+def frame_rows(zaxis, xaxis):
+    return np.array([xaxis, np.cross(zaxis, xaxis), zaxis])
+
+
+# einsum signatures of the two rotations, for one vector and for an (n, 3) array of them
+_TO_EXTERNAL = {1: 'ij,i->j', 2: 'ij,ki->kj'}
+_TO_LOCAL = {1: 'ji,i->j', 2: 'ji,ki->kj'}
+_AXIS_ROW = {'xaxis': 0, 'yaxis': 1, 'zaxis': 2}
+
+
 class GeometryObject(ConfigObject):
     """An object with a position and an orientation in 3D."""
 
     def __getattr__(self, key):
-        if key in ('xaxis', 'yaxis', 'zaxis'):
-            try:
-                orientation = self.__dict__['orientation']
-            except KeyError:
-                raise AttributeError(key)
-            return orientation['xyz'.index(key[0]), :]
+        # xaxis / yaxis / zaxis are views of the frame, available once setup() has built it
+        if key in _AXIS_ROW and 'orientation' in self.__dict__:
+            return self.__dict__['orientation'][_AXIS_ROW[key], :]
         raise AttributeError(key)
 
     def default_config(self):
@@ -92,65 +117,47 @@ class GeometryObject(ConfigObject):
         return config
 
     def check_config(self):
-        if self.config['xaxis'] is not None:
-            zaxis = np.array(self.config['zaxis'])
-            xaxis = np.array(self.config['xaxis'])
-            if not np.isclose(np.dot(zaxis, xaxis), 0.0):
-                raise ValueError('zaxis and xaxis are not orthogonal.')
+        given = self.config['xaxis']
+        if given is not None and not np.isclose(np.dot(np.array(self.config['zaxis']), np.array(given)), 0.0):
+            raise ValueError('zaxis and xaxis are not orthogonal.')
 
     def setup(self):
         super().setup()
-        self.param['origin'] = np.array(self.param['origin'])
-        self.param['zaxis'] = np.array(self.param['zaxis'])
-        if self.param['xaxis'] is None:
-            self.param['xaxis'] = self.get_default_xaxis(self.param['zaxis'])
-        else:
-            self.param['xaxis'] = np.array(self.param['xaxis'])
-        self.origin = self.param['origin']
-        self.set_orientation(self.param['zaxis'], self.param['xaxis'])
+        p = self.param
+        for key in ('origin', 'zaxis'):
+            p[key] = np.array(p[key])
+        p['xaxis'] = default_xaxis(p['zaxis']) if p['xaxis'] is None else np.array(p['xaxis'])
+        self.origin = p['origin']
+        self.orientation = frame_rows(p['zaxis'], p['xaxis'])
 
     def set_orientation(self, zaxis, xaxis=None):
-        if xaxis is None:
-            xaxis = self.get_default_xaxis(zaxis)
-        self.orientation = np.array([xaxis, np.cross(zaxis, xaxis), zaxis])
+        self.orientation = frame_rows(zaxis, default_xaxis(zaxis) if xaxis is None else xaxis)
 
     def get_default_xaxis(self, zaxis):
-        xaxis = np.cross(np.array([0.0, 0.0, 1.0]), zaxis)
-        if not np.all(xaxis == 0.0):
-            xaxis /= np.linalg.norm(xaxis)
-        else:
-            xaxis = np.array([1.0, 0.0, 0.0])
-        return xaxis
+        return default_xaxis(zaxis)
 
-    # -- transforms (host-side conveniences; act in place like the reference) --
+    # -- transforms (host-side conveniences; they act in place unless copy=True, like the reference's) --
 
     @staticmethod
     def to_ndarray(vector_in):
-        if not isinstance(vector_in, np.ndarray):
-            vector_in = np.array(vector_in, dtype=np.float64)
-        return vector_in
+        return vector_in if isinstance(vector_in, np.ndarray) else np.array(vector_in, dtype=np.float64)
 
     def to_vector_array(self, vector_in):
-        vector_in = self.to_ndarray(vector_in)
-        return vector_in[None, :] if vector_in.ndim < 2 else vector_in
+        v = self.to_ndarray(vector_in)
+        return v if v.ndim >= 2 else v[None, :]
 
-    def _rotate(self, vector, spec2, spec1, copy):
-        if copy:
-            vector = _copy.copy(vector)
-        vector = self.to_ndarray(vector)
-        if vector.ndim == 2:
-            vector[:] = np.einsum(spec2, self.orientation, vector)
-        elif vector.ndim == 1:
-            vector[:] = np.einsum(spec1, self.orientation, vector)
-        else:
+    def _rotated(self, vector, signatures, copy):
+        v = self.to_ndarray(_copy.copy(vector) if copy else vector)
+        if v.ndim not in signatures:
             raise Exception('vector.ndim must be 1 or 2')
-        return vector
+        v[:] = np.einsum(signatures[v.ndim], self.orientation, v)
+        return v
 
     def vector_to_external(self, vector, copy=False):
-        return self._rotate(vector, 'ij,ki->kj', 'ij,i->j', copy)
+        return self._rotated(vector, _TO_EXTERNAL, copy)
 
     def vector_to_local(self, vector, copy=False):
-        return self._rotate(vector, 'ji,ki->kj', 'ji,i->j', copy)
+        return self._rotated(vector, _TO_LOCAL, copy)
 
     def point_to_external(self, point_local, copy=False):
         return self.vector_to_external(point_local, copy=copy) + self.origin
@@ -158,31 +165,38 @@ class GeometryObject(ConfigObject):
     def point_to_local(self, point_external, copy=False):
         return self.vector_to_local(point_external - self.origin, copy=copy)
 
-    def ray_to_external(self, ray_local, copy=False):
-        ray = _copy.deepcopy(ray_local) if copy else ray_local
-        ray['origin'] = self.point_to_external(ray['origin'])
-        ray['direction'] = self.vector_to_external(ray['direction'])
+    def _ray_moved(self, ray, point_fn, vector_fn, copy):
+        ray = _copy.deepcopy(ray) if copy else ray
+        ray['origin'] = point_fn(ray['origin'])
+        ray['direction'] = vector_fn(ray['direction'])
         return ray
 
+    def ray_to_external(self, ray_local, copy=False):
+        return self._ray_moved(ray_local, self.point_to_external, self.vector_to_external, copy)
+
     def ray_to_local(self, ray_external, copy=False):
-        ray = _copy.deepcopy(ray_external) if copy else ray_external
-        ray['origin'] = self.point_to_local(ray['origin'])
-        ray['direction'] = self.vector_to_local(ray['direction'])
-        return ray
+        return self._ray_moved(ray_external, self.point_to_local, self.vector_to_local, copy)
 
     def aim_to_point(self, aim_point, xaxis=None):
         zaxis = aim_point - self.origin
         zaxis /= np.linalg.norm(zaxis)
-        if xaxis is None:
-            xaxis = self.get_default_xaxis(zaxis)
-        return {'zaxis': zaxis, 'xaxis': xaxis}
+        return {'zaxis': zaxis, 'xaxis': default_xaxis(zaxis) if xaxis is None else xaxis}
 
 
-_SHORT = {'O': 'origin', 'D': 'direction', 'W': 'wavelength', 'M': 'mask'}
+# ---------------------------------------------------------------------------
+# ray arrays
+# ---------------------------------------------------------------------------
+
+# field -> (shape behind the ray axis, dtype, value of a missing field); `weight` rides along when present
+# but is not one of the four fields the reference's RayArray knows about (xicsrt/objects/_RayArray.py:12-96)
+_RAY_FIELDS = {'origin': ((3,), np.float64, None), 'direction': ((3,), np.float64, None),
+               'mask': ((), bool, True), 'wavelength': ((), np.float64, 0.0)}
+_RAY_ALIAS = {'O': 'origin', 'D': 'direction', 'W': 'wavelength', 'M': 'mask'}
 
 
 class RayArray(dict):
-    """Dictionary of per-ray ndarrays: origin (N,3), direction (N,3), wavelength (N,), mask (N,)."""
+    """Dictionary of per-ray ndarrays: origin (N,3), direction (N,3), wavelength (N,), mask (N,),
+    also reachable as attributes (`rays.origin`, `rays.O`, ...)."""
 
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
@@ -190,45 +204,38 @@ class RayArray(dict):
             self.initialize()
 
     def initialize(self):
-        if not (('origin' in self) and ('direction' in self)):
+        """Fill in what is missing (mask: all rays on, wavelength: 0) and make every field an ndarray."""
+        if 'origin' not in self or 'direction' not in self:
             raise Exception('Cannot initialize, origin and direction must be present.')
-        for key in ('origin', 'direction'):
-            if not isinstance(self[key], np.ndarray):
-                self[key] = np.array(self[key])
-        num = self['origin'].shape[0]
-        if 'mask' not in self:
-            self['mask'] = np.ones(num, dtype=bool)
-        if 'wavelength' not in self:
-            self['wavelength'] = np.zeros(num)
-        for key in ('mask', 'wavelength'):
-            if not isinstance(self[key], np.ndarray):
-                self[key] = np.array(self[key])
+        count = np.shape(self['origin'])[0]
+        for name, (tail, dtype, fill) in _RAY_FIELDS.items():
+            if name not in self:
+                self[name] = np.full((count,) + tail, fill, dtype=dtype)
+            elif not isinstance(self[name], np.ndarray):
+                self[name] = np.array(self[name])
 
     def __getattribute__(self, key):
-        full = _SHORT.get(key, key)
-        if full in ('origin', 'direction', 'wavelength', 'mask'):
-            return self[full]
+        name = _RAY_ALIAS.get(key, key)
+        if name in _RAY_FIELDS:
+            return self[name]
         return super().__getattribute__(key)
 
     def __setattr__(self, key, value):
-        full = _SHORT.get(key, key)
-        if full in ('origin', 'direction', 'wavelength', 'mask'):
-            self[full] = value
+        name = _RAY_ALIAS.get(key, key)
+        if name in _RAY_FIELDS:
+            self[name] = value
         else:
             super().__setattr__(key, value)
 
     def zeros(self, num):
-        self['origin'] = np.zeros((num, 3))
-        self['direction'] = np.zeros((num, 3))
-        self['mask'] = np.zeros((num), dtype=bool)
-        self['wavelength'] = np.zeros((num))
+        """`num` rays, all fields zero (mask off)."""
+        for name, (tail, dtype, _) in _RAY_FIELDS.items():
+            self[name] = np.zeros((num,) + tail, dtype=dtype)
 
     def copy(self):
-        new = RayArray()
-        for key in self:
-            new[key] = self[key].copy()
-        return new
+        return RayArray({name: values.copy() for name, values in self.items()})
 
     def extend(self, ray_in):
-        for key in self:
-            self[key] = np.concatenate((self[key], ray_in[key]))
+        """Append the rays of `ray_in` (fields this array does not have are ignored)."""
+        for name in list(self):
+            self[name] = np.concatenate((self[name], ray_in[name]))

@@ -181,19 +181,19 @@ class ShapeMeshSphere(ShapeMesh):
          p['mesh_coarse_faces']) = self.generate_mesh(p['mesh_coarse_size'])
 
     def generate_mesh(self, meshsize):
+        """Grid over the (x, y) footprint, lifted onto the sphere that touches the local origin from above.
+        (The products below are fed to the device bit for bit, so the expressions keep the operand order of
+        xicsrt/optics/_ShapeMeshSphere.py:60-98: r - sqrt(r^2 - x^2 - y^2), normal = (centre - point) / length.)"""
         from scipy.spatial import Delaunay
-        p = self.param
-        xsize, ysize = p['xsize'], p['ysize']
-        x = np.linspace(-xsize / 2, xsize / 2, int(meshsize[0]))
-        y = np.linspace(-ysize / 2, ysize / 2, int(meshsize[1]))
-        center = np.array([0.0, 0.0, p['radius']])
-        xx, yy = np.meshgrid(x, y)
-        zz = p['radius'] - np.sqrt(p['radius'] ** 2 - xx ** 2 - yy ** 2)
-        points = np.stack((xx.flatten(), yy.flatten(), zz.flatten())).T
-        norm = center - points
-        norm /= np.expand_dims(np.linalg.norm(norm, axis=1), 1)
-        faces = Delaunay(points[:, 0:2]).simplices
-        return points, norm, faces
+        radius = self.param['radius']
+        half = (self.param['xsize'] / 2, self.param['ysize'] / 2)
+        gx, gy = np.meshgrid(np.linspace(-half[0], half[0], int(meshsize[0])),
+                             np.linspace(-half[1], half[1], int(meshsize[1])))
+        sag = radius - np.sqrt(radius ** 2 - gx ** 2 - gy ** 2)
+        points = np.stack((gx.flatten(), gy.flatten(), sag.flatten())).T
+        inward = np.array([0.0, 0.0, radius]) - points
+        inward /= np.expand_dims(np.linalg.norm(inward, axis=1), 1)
+        return points, inward, Delaunay(points[:, 0:2]).simplices
 
 
 class ShapeMeshCylinder(_GridMesh):
@@ -224,14 +224,14 @@ class ShapeMeshCylinder(_GridMesh):
         return self.param['x_range'], self.param['angle_range']
 
     def surface(self, x, angle):
-        C0 = np.array([0.0, 0.0, 0.0])
-        C0_zaxis = np.array([0.0, 0.0, 1.0])
-        C0_xaxis = np.array([1.0, 0.0, 0.0])
+        """Point and inward normal at axial position x and angle about the cylinder axis (local x, through
+        (0, 0, radius)).  Operand order as in xicsrt/optics/_ShapeMeshCylinder.py:150-192: the axis point is
+        0 + radius * z + (x, 0, 0) and the surface point is that minus radius * normal."""
         radius = self.param['radius']
-        x_vec = np.array([x, 0.0, 0.0])
-        O = C0 + radius * C0_zaxis + x_vec
-        X_norm = _vector_rotate(C0_zaxis, C0_xaxis, angle)
-        return O - radius * X_norm, X_norm
+        up, along = np.array([0.0, 0.0, 1.0]), np.array([1.0, 0.0, 0.0])
+        on_axis = np.array([0.0, 0.0, 0.0]) + radius * up + np.array([x, 0.0, 0.0])
+        normal = _vector_rotate(up, along, angle)
+        return on_axis - radius * normal, normal
 
 
 class ShapeMeshTorus(_GridMesh):
@@ -274,16 +274,18 @@ class ShapeMeshTorus(_GridMesh):
         return self.param['angle_major'], self.param['angle_minor']
 
     def surface(self, a, b):
+        """Point and normal at major angle a (about local y) and minor angle b (about the tube's tangent).
+        Two rotations: `up` about y by a gives the direction from the torus centre line to the tube centre,
+        that direction about the tube's tangent by b gives the surface normal.  The sign pair (major, minor)
+        selects which of the four torus patches faces the origin.  Operand order as in
+        xicsrt/optics/_ShapeMeshTorus.py:132-160 (the generated points are compared bit for bit)."""
         p = self.param
-        C0_zaxis = np.asarray([0.0, 0.0, 1.0])
-        C0_xaxis = np.asarray([1.0, 0.0, 0.0])
-        s_maj, s_min = p['torus_sign_major'], p['torus_sign_minor']
-        r_maj, r_min = p['radius_major'], p['radius_minor']
-        C0_yaxis = np.cross(C0_zaxis, C0_xaxis)
-        center = r_maj * C0_zaxis * s_maj
-        C_norm = _vector_rotate(C0_zaxis, C0_yaxis, a)
-        C = center - r_maj * C_norm * s_maj
-        Q = C + r_min * C_norm * s_min
-        axis = np.cross(C_norm * s_min, C0_yaxis)
-        X_norm = _vector_rotate(C_norm * s_min, axis, b)
-        return Q - X_norm * r_min, X_norm
+        sign_major, sign_minor = p['torus_sign_major'], p['torus_sign_minor']
+        big, small = p['radius_major'], p['radius_minor']
+        up = np.asarray([0.0, 0.0, 1.0])
+        hinge = np.cross(up, np.asarray([1.0, 0.0, 0.0]))              # local y: axis of the major circle
+        spoke = _vector_rotate(up, hinge, a)
+        tube_centre = big * up * sign_major - big * spoke * sign_major + small * spoke * sign_minor
+        tangent = np.cross(spoke * sign_minor, hinge)
+        normal = _vector_rotate(spoke * sign_minor, tangent, b)
+        return tube_centre - normal * small, normal

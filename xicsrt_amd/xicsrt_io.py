@@ -7,8 +7,11 @@ Files of the drop-in boundary: config / results dictionaries and detector images
   save_images                    one image file per optic that made an image (PIL, rot90 as the reference)
   generate_filename              '<prefix>_<name>_<suffix>_<run_suffix><ext>' under output_path
 
-hdf5 (the reference's default `results_ext`, through its own util/mirhdf5 on h5py) is only
-available when h5py is importable; this image has no h5py, so '.hdf5' raises with that message.
+hdf5 (the reference's default `results_ext`) is written and read in the on-disk layout of the
+reference's util/mirhdf5 (xicsrt/util/mirhdf5.py:58-330: one group per dict with its key order as an
+attribute, lists as groups of '0000', '0001', ..., None and str marked by attributes) through h5py,
+which is imported on demand.  Without h5py, hdf5 targets are refused up front by `require_writable`
+(called from check_config before anything is traced), not after the work is done.
 """
 import copy
 import json
@@ -71,6 +74,106 @@ def _make_parent(filename):
         log.info(f'Made directory: {path}')
 
 
+# ---------------------------------------------------------------------------
+# hdf5, mirhdf5 layout
+# ---------------------------------------------------------------------------
+
+_H5_TYPE = '_mirhdf5 python object type'
+_H5_ORDER = '_mirhdf5 dictionary order'
+_H5_NONE = '_mirhdf5 python None'
+_H5_STR = '_mirhdf5 python str'
+
+
+def _h5py():
+    try:
+        import h5py
+    except ImportError:
+        raise ImportError("hdf5 files need the h5py package, which is not installed; set general.results_ext "
+                          "(or config_ext) to '.json' or '.pickle'") from None
+    return h5py
+
+
+def is_hdf5(ext):
+    return 'hdf5' in ext or 'h5' in ext
+
+
+def require_writable(ext):
+    """Raise now (before any tracing) when files with extension `ext` cannot be written here."""
+    if is_hdf5(ext):
+        _h5py()
+    elif not ('pickle' in ext or 'pkl' in ext or 'json' in ext):
+        raise NotImplementedError(f'filetype: {ext} not currently supported.')
+
+
+def _h5_put(group, key, item):
+    if isinstance(item, dict):
+        sub = group.create_group(key)
+        sub.attrs[_H5_TYPE] = b'dict'
+        try:
+            sub.attrs[_H5_ORDER] = [k.encode() for k in item]
+        except (TypeError, AttributeError):
+            log.error('Could not save dictionary key order. keys of unsupported data type.')
+        for k, v in item.items():
+            _h5_put(sub, k, v)
+    elif isinstance(item, list):
+        sub = group.create_group(key)
+        sub.attrs[_H5_TYPE] = b'list'
+        for i, v in enumerate(item):
+            _h5_put(sub, '{:04d}'.format(i), v)
+    elif item is None:
+        group[key] = False
+        group[key].attrs[_H5_NONE] = True
+    else:
+        try:
+            group.create_dataset(key, data=item)
+            if isinstance(item, str):
+                group[key].attrs[_H5_STR] = True
+        except TypeError:
+            log.exception('Could not add key "{}" of type {} to hdf5 file.'.format(key, type(item)))
+
+
+def dict_to_hdf5(data, filename):
+    """Write a (nested) dict with string keys as an hdf5 file the reference's mirhdf5.hdf5ToDict reads back."""
+    h5py = _h5py()
+    if not isinstance(data, dict):
+        raise Exception('Incorrect input type. Dictionary expected.')
+    with h5py.File(filename, 'w') as ff:
+        ff.attrs[_H5_TYPE] = b'dict'
+        ff.attrs[_H5_ORDER] = [k.encode() for k in data]
+        for k, v in data.items():
+            _h5_put(ff, k, v)
+
+
+def _h5_get(node, h5py):
+    attrs = node.attrs
+    if isinstance(node, h5py.Group):
+        kind = attrs.get(_H5_TYPE, b'dict')
+        kind = kind.decode() if hasattr(kind, 'decode') else kind
+        if kind == 'dict':
+            keys = attrs[_H5_ORDER] if _H5_ORDER in attrs else list(node.keys())
+            out = {}
+            for k in keys:
+                k = k.decode() if hasattr(k, 'decode') else k
+                out[k] = _h5_get(node[k], h5py)
+            return out
+        if kind == 'list':
+            return [_h5_get(node[k], h5py) for k in node.keys()]
+        raise Exception('Unknown group type: {}'.format(kind))
+    if _H5_NONE in attrs:
+        return None
+    value = node[()]
+    if _H5_STR in attrs:
+        value = value.decode()
+    return value
+
+
+def hdf5_to_dict(filename):
+    """Read an hdf5 file written by dict_to_hdf5 or by the reference's mirhdf5.dictToHdf5."""
+    h5py = _h5py()
+    with h5py.File(filename, 'r') as ff:
+        return _h5_get(ff, h5py)
+
+
 def read_dict(filename):
     filename = pathlib.Path(filename).expanduser()
     ext = filename.suffix
@@ -81,7 +184,7 @@ def read_dict(filename):
         with open(filename, 'r') as ff:
             return lists_to_numpy(json.load(ff))
     if 'hdf5' in ext or 'h5' in ext:
-        raise NotImplementedError('hdf5 files need h5py, which is not installed here; use .json or .pickle')
+        return hdf5_to_dict(filename)
     raise NotImplementedError(f'filetype: {ext} not currently supported.')
 
 
@@ -99,8 +202,7 @@ def write_dict(data, filename, mkdir=False, overwrite=False):
         with open(filename, 'w') as ff:
             json.dump(numpy_to_lists(copy.deepcopy(data)), ff, indent=2)
     elif 'hdf5' in ext or 'h5' in ext:
-        raise NotImplementedError('hdf5 files need h5py, which is not installed here; set results_ext to '
-                                  "'.json' or '.pickle'")
+        dict_to_hdf5(data, filename)
     else:
         raise NotImplementedError(f'filetype: {ext} not currently supported.')
 

@@ -162,12 +162,19 @@ def _check_seed(seed):
 
 def check_config(config):
     """Output directory must exist when anything is to be saved (xicsrt_raytrace.py:396-411)."""
-    do_save = any(config['general'][key] for key in config['general'] if 'save' in key)
+    general = config['general']
+    do_save = any(general[key] for key in general if 'save' in key)
     if do_save:
-        path = config['general']['output_path']
+        path = general['output_path']
         if path is None or not os.path.exists(path):
-            if not config['general']['make_directories']:
+            if not general['make_directories']:
                 raise Exception('Output directory does not exist. Create directory or set make_directories to True.')
+    # a file type that cannot be written here (hdf5, the default results_ext, without h5py) is refused before
+    # the trace, not after it
+    if general.get('save_results'):
+        xicsrt_io.require_writable(general['results_ext'])
+    if general.get('save_config'):
+        xicsrt_io.require_writable(general['config_ext'])
 
 
 # ---------------------------------------------------------------------------
