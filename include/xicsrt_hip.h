@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define XRT_ABI_VERSION 11
+#define XRT_ABI_VERSION 12
 
 #define XRT_MAX_OPTICS     16
 #define XRT_MAX_APERTURES  8
@@ -348,6 +348,19 @@ int xrt_make_image(const xrt_optic_t* optic, int64_t n, const double* rays, cons
  * _XicsrtSourceGeneric.py:193-194); -8 the candidate reserve of the Gaussian wavelength sampler was
  * exhausted (a > 8 sigma event).  0 = clean. */
 int xrt_check(void* workspace, void* stream);
+
+/* Diagnostics: the device routes taken by this thread's xrt_trace / xrt_trace_history calls since the last
+ * call with reset != 0 (bit set below).  The routes are picked per scene; the environment switches
+ * XICSRT_NO_JUMP, XICSRT_NO_STAGE_SPLIT, XICSRT_STAGED_GAUSS, XICSRT_SEGMENTS force the fallbacks and are read
+ * at every call.  No reference counterpart. */
+#define XRT_PATH_FUSED          1u   /* source -> optics -> histogram in one kernel                    */
+#define XRT_PATH_STAGED         2u   /* array-at-a-time passes over a ray SoA in HBM                    */
+#define XRT_PATH_STAGE_SPLIT    4u   /* staged: source and optics as two launches per batch of runs     */
+#define XRT_PATH_JUMP           8u   /* MT19937 heads positioned by polynomial jump-ahead               */
+#define XRT_PATH_SEEK          16u   /* heads positioned by walking the stream                          */
+#define XRT_PATH_SEGMENTED     32u   /* runs split into segments (few runs of many rays)                */
+#define XRT_PATH_GAUSS_PREPARED 64u  /* np.random.normal wavelengths prepared as an array               */
+uint32_t xrt_last_path(int32_t reset);
 
 /* Diagnostic, host only: the MT19937 jump-ahead polynomial g(t) = t^J mod phi(t)
  * (phi = characteristic polynomial of the generator, degree 19937) that positions

@@ -275,14 +275,33 @@ def test_gaussian_wavelengths_with_a_cached_value_pending():
 def test_alternative_device_paths_equal_reference(name, env, monkeypatch):
     """The library's fallbacks (sequential walk instead of jump-ahead, one-launch staged kernel, staged Gaussian
     wavelengths) are alternative routes to the same integers."""
-    monkeypatch.setenv(env, '1')
+    from xicsrt_amd import capi
     cfg, gold = helpers.load_golden(name)
     config, elements, flat = helpers.build(cfg)
     g = config['general']
     seeds = xrt.run_seeds(g['random_seed'], g['number_of_runs'])
+    lib = capi.lib()
+    # the route the scene takes by itself, then the one the switch forces: they must differ where the
+    # switch applies to the scene (the switches are read at every call, not latched at first use)
+    dev0 = xrt.DeviceTrace(flat)
+    lib.xrt_last_path(1)
+    dev0.trace(seeds, g['number_of_iter'], keep_images=True)
+    dev0.results()
+    default_path = lib.xrt_last_path(1)
+    monkeypatch.setenv(env, '1')
     dev = xrt.DeviceTrace(flat)
     dev.trace(seeds, g['number_of_iter'], keep_images=True)
     meta, image = dev.results()
+    forced_path = lib.xrt_last_path(1)
+    if env == 'XICSRT_NO_JUMP' and (default_path & capi.PATH_FUSED):
+        # heads by walking the stream; a scene whose Gaussian wavelengths were prepared through jump-positioned
+        # chunk heads goes to the staged path instead
+        assert (default_path & capi.PATH_JUMP) and not (forced_path & (capi.PATH_JUMP | capi.PATH_SEGMENTED))
+        assert forced_path & (capi.PATH_SEEK | capi.PATH_STAGED)
+    if env == 'XICSRT_NO_STAGE_SPLIT' and (default_path & capi.PATH_STAGED):
+        assert (default_path & capi.PATH_STAGE_SPLIT) and not (forced_path & capi.PATH_STAGE_SPLIT)
+    if env == 'XICSRT_STAGED_GAUSS' and (default_path & capi.PATH_GAUSS_PREPARED):
+        assert (forced_path & capi.PATH_STAGED) and not (forced_path & capi.PATH_GAUSS_PREPARED)
     for nm in flat.names:
         assert int(meta[nm]['num_out']) == int(gold['num_out/' + nm]), nm
     for nm in flat.names[1:]:

@@ -1555,6 +1555,11 @@ static int fail(int code, const char* fmt, const char* a = "")
         if (e_ != hipSuccess) return fail(-10, #expr ": %s", hipGetErrorString(e_)); \
     } while (0)
 
+// Which device routes the calls of this thread took since the last xrt_last_path(1): tests of the
+// fallback switches (environment variables, read at every call) assert on it.
+static thread_local uint32_t g_paths = 0;
+static bool env_on(const char* name) { return getenv(name) != nullptr; }
+
 static bool timing_on = false;
 static double timing_ms = 0.0;
 static int64_t timing_launches = 0;
@@ -2249,8 +2254,9 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
             special = special || sc->optics[e].interact == XRT_INTERACT_MOSAIC || sc->optics[e].shape == XRT_SHAPE_MESH ||
                       (sc->optics[e].flags & XRT_F_TRACE_LOCAL);
         if (src == 2 && !hist) return fail(-2, "%s", "external rays are traced through xrt_trace_history");
-        static const bool no_split = getenv("XICSRT_NO_STAGE_SPLIT") != nullptr;
-        if (src != 2 && !hist && !no_split) {
+        g_paths |= XRT_PATH_STAGED;
+        if (src != 2 && !hist && !env_on("XICSRT_NO_STAGE_SPLIT")) {
+            g_paths |= XRT_PATH_STAGE_SPLIT;
             // source and optics in separate launches, a batch of `slots` runs at a time
             g.n_src_slot = reinterpret_cast<int64_t*>(g.bundle_off + (size_t)slots * XRT_ST_BUNDLE_ROWS * (size_t)(sc->source.bundle_count > 0 ? sc->source.bundle_count : 0));
             void (*k1)(const KScene*, const KArgs, const KStaged) = src == 1 ? xrt_staged_kernel<false, 1, false, 1>
@@ -2289,6 +2295,7 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
     const SegPlan plan = ahead > 0 ? plan_segments(sc, n_runs) : SegPlan{1, 0, 0, 0, 0};
     if (seg_active(plan)) {
         // ---- segmented runs -------------------------------------------------------------------------
+        g_paths |= XRT_PATH_FUSED | XRT_PATH_SEGMENTED | XRT_PATH_JUMP;
         const int S = plan.n_seg, nj = seg_jobs(sc, plan);
         const int64_t L = plan.seg_len, CH = 2 * L;
         int be = -1;
@@ -2377,6 +2384,7 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
         a.run_stride = nj;
         a.wl_array = nullptr; a.base_words = nullptr;
         if (n_gch > 0) {
+            g_paths |= XRT_PATH_GAUSS_PREPARED;
             // np.random.normal wavelengths of every run as an array (count pass only when a run has several chunks)
             KGauss gk;
             memset(&gk, 0, sizeof(gk));
@@ -2413,8 +2421,9 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
         }
         return 0;
     }
-    static const bool no_jump = getenv("XICSRT_NO_JUMP") != nullptr;
-    if (canonical && !no_jump && N >= (int64_t)XRT_AHEAD / 2) {
+    g_paths |= XRT_PATH_FUSED;
+    if (canonical && !env_on("XICSRT_NO_JUMP") && N >= (int64_t)XRT_AHEAD / 2) {
+        g_paths |= XRT_PATH_JUMP;
         static thread_local std::vector<uint32_t> hpolys;
         hpolys.clear();
         int n_polys = 0;
@@ -2438,6 +2447,7 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
                            ks.src.n_arrays, ks.src.array_used, nh, n_polys, N);
         HIP_TRY(hipGetLastError());
     } else {
+        g_paths |= XRT_PATH_SEEK;
         hipLaunchKernelGGL(xrt_seek_kernel, dim3((n_runs + 3) / 4), dim3(256), 0, stream,
                            streams, heads, n_runs, ks.src.n_arrays, ks.src.array_used, nh, N);
         HIP_TRY(hipGetLastError());
@@ -2584,6 +2594,13 @@ extern "C" int xrt_make_image(const xrt_optic_t* optic, int64_t n, const double*
                        reinterpret_cast<unsigned long long*>(images));
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+extern "C" uint32_t xrt_last_path(int32_t reset)
+{
+    const uint32_t p = g_paths;
+    if (reset) g_paths = 0;
+    return p;
 }
 
 extern "C" int xrt_check(void* workspace, void* stream_)
