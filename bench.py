@@ -76,21 +76,20 @@ def cpu_baseline(flat, n_rays, target_seconds=8.0):
                       % (runs, n_rays, threads, dt)}
 
 
-def measured_traffic(rays, runs):
-    """HBM bytes per launch of the propagation kernel from the committed rocprofv3 counter passes
-    (profiles/*.json written by profiles/run_profile.sh for the same workload), newest first."""
+def committed_profile(rays, runs):
+    """The newest committed rocprofv3 summary (profiles/r*.json, written by profiles/run_profile.sh) of this
+    workload: HBM bytes per launch of the propagation kernel from the FETCH_SIZE / WRITE_SIZE passes and the
+    SQ issue counters of one launch."""
     import glob
-    best = None
     for fn in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*.json')), reverse=True):
         try:
             d = json.load(open(fn))
             cfg = d.get('bench_fetch', {}).get('config', {})
             if cfg.get('rays_per_run') == rays and cfg.get('runs_per_gpu') == runs and 'hbm_traffic_bytes_per_launch' in d:
-                best = (d['hbm_traffic_bytes_per_launch'], os.path.relpath(fn, ROOT))
-                break
+                return d, os.path.relpath(fn, ROOT)
         except Exception:
             continue
-    return best
+    return None, None
 
 
 def main():
@@ -101,6 +100,8 @@ def main():
     ap.add_argument('--runs', type=int, default=1000, help='runs per step and per GPU')
     ap.add_argument('--rays', type=int, default=1000000, help='rays per run')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak',
+                    help='weak: every rank traces --runs runs; strong: --runs runs in total, sharded over the ranks')
     args = ap.parse_args()
 
     import numpy as np
@@ -122,7 +123,7 @@ def main():
         torch.cuda.set_device(0)
     lib = capi.lib()
 
-    total_runs = args.runs * world
+    total_runs = args.runs * world if args.scaling == 'weak' else args.runs
     config = xconfig.get_config(spectrometer_config(args.rays, total_runs))
     elements = xrt.Elements(config)
     flat = elements.flatten()
@@ -173,12 +174,13 @@ def main():
         line = {
             'metric': 'Mphotons/sec (launched->detector) 3-element crystal spectrometer',
             'value': value, 'unit': 'Mphotons/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'cfg3: XicsrtSourceDirected(point, spread 10deg) -> XicsrtOpticSphericalCrystal'
                                    '(gaussian rocking curve) -> XicsrtOpticDetector; %d rays/run x %d runs/GPU, '
-                                   '1 iteration, keep_history=False, keep_images=True' % (args.rays, args.runs),
-                       'rays_per_run': args.rays, 'runs_per_gpu': args.runs, 'photons_per_step': photons_per_step,
+                                   '1 iteration, keep_history=False, keep_images=True' % (args.rays, len(my_seeds)),
+                       'rays_per_run': args.rays, 'runs_per_gpu': len(my_seeds), 'photons_per_step': photons_per_step,
+                       'rccl_ranks': (dist.get_world_size() if use_dist else 0),
                        'parallelism': 'runs sharded i mod N, one all-reduce of u64 histogram+counters per step',
                        'num_out': {n: int(v) for n, v in zip(flat.names, num_out)}},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -187,10 +189,30 @@ def main():
                          'algorithmic_bytes_per_photon': ALGO_BYTES_PER_PHOTON,
                          'photons_per_launch': per_launch_photons},
         }
-        traffic = measured_traffic(args.rays, args.runs)
-        if traffic is not None:
-            line['roofline']['traffic'] = traffic[0]
-            line['roofline']['traffic_source'] = traffic[1]
+        prof, prof_file = committed_profile(args.rays, args.runs)
+        if prof is not None:
+            # `frac` above prices the ALGORITHMIC bytes (what a ray-SoA-in-HBM design would move); the fused
+            # kernel keeps rays in registers / LDS, so the bytes that really cross the HBM interface are the
+            # pixel atomics: reported next to it, with the rate they amount to.
+            line['roofline']['traffic'] = prof['hbm_traffic_bytes_per_launch']
+            line['roofline']['traffic_source'] = prof_file
+            line['roofline']['hbm_measured_GBps'] = prof['hbm_traffic_bytes_per_launch'] / kavg_s / 1e9 if kavg_s > 0 else None
+            line['roofline']['hbm_measured_frac_of_peak'] = (line['roofline']['hbm_measured_GBps'] or 0.0) / HBM_PEAK_GBS
+            sqd = prof.get('sq_derived') or {}
+            if 'valu_wave_instr_per_64_photons' in sqd:
+                # the real limiter: vector-instruction issue (binary64 geometry + MT19937), from the committed
+                # SQ pass of the same command; `achieved` = wave-instructions issued per second on this run
+                vpp = sqd['valu_wave_instr_per_64_photons'] / 64.0
+                clock = sqd.get('clock_GHz_under_load', 2.4)
+                issued = vpp * per_launch_photons / kavg_s if kavg_s > 0 else 0.0
+                peak = 1024.0 * clock * 1e9 / 4.0          # 1024 SIMDs, one wave64 VALU instruction per 4 cycles
+                line['roofline_valu'] = {
+                    'bound': 'valu_issue', 'achieved': issued / 1e9, 'peak': peak / 1e9, 'unit': 'G wave-instr/s',
+                    'frac': issued / peak if peak > 0 else None,
+                    'valu_wave_instr_per_photon': vpp, 'clock_GHz_under_load': clock,
+                    'busy_fraction_in_profile_pass': sqd.get('valu_issue_busy_fraction'),
+                    'source': prof_file}
+                line['roofline']['limiter'] = 'valu_issue (see roofline_valu); HBM carries only the histogram atomics'
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(flat, args.rays)
         print(json.dumps(line))
