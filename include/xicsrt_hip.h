@@ -360,6 +360,7 @@ int xrt_check(void* workspace, void* stream);
 #define XRT_PATH_SEEK          16u   /* heads positioned by walking the stream                          */
 #define XRT_PATH_SEGMENTED     32u   /* runs split into segments (few runs of many rays)                */
 #define XRT_PATH_GAUSS_PREPARED 64u  /* np.random.normal wavelengths prepared as an array               */
+#define XRT_PATH_PLASMA_SCOUT 128u   /* plasma source: stream walked by one wave per run, rays rebuilt in the fused kernel */
 uint32_t xrt_last_path(int32_t reset);
 
 /* Diagnostic, host only: the MT19937 jump-ahead polynomial g(t) = t^J mod phi(t)

@@ -270,8 +270,9 @@ def test_gaussian_wavelengths_with_a_cached_value_pending():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('env', ['XICSRT_NO_JUMP', 'XICSRT_NO_STAGE_SPLIT', 'XICSRT_STAGED_GAUSS'])
-@pytest.mark.parametrize('name', ['C_sphere_runs_iters', 'W_normal_1e5', 'F_plasma_counts', 'Q_four_counts', 'B_mirror_runs'])
+@pytest.mark.parametrize('env', ['XICSRT_NO_JUMP', 'XICSRT_NO_STAGE_SPLIT', 'XICSRT_STAGED_GAUSS', 'XICSRT_PLASMA_STAGED'])
+@pytest.mark.parametrize('name', ['C_sphere_runs_iters', 'W_normal_1e5', 'F_plasma_counts', 'F_datafile_filter_counts',
+                                  'Q_four_counts', 'B_mirror_runs'])
 def test_alternative_device_paths_equal_reference(name, env, monkeypatch):
     """The library's fallbacks (sequential walk instead of jump-ahead, one-launch staged kernel, staged Gaussian
     wavelengths) are alternative routes to the same integers."""
@@ -293,13 +294,23 @@ def test_alternative_device_paths_equal_reference(name, env, monkeypatch):
     dev.trace(seeds, g['number_of_iter'], keep_images=True)
     meta, image = dev.results()
     forced_path = lib.xrt_last_path(1)
-    if env == 'XICSRT_NO_JUMP' and (default_path & capi.PATH_FUSED):
+    if env == 'XICSRT_NO_JUMP' and (default_path & capi.PATH_JUMP):
         # heads by walking the stream; a scene whose Gaussian wavelengths were prepared through jump-positioned
         # chunk heads goes to the staged path instead
-        assert (default_path & capi.PATH_JUMP) and not (forced_path & (capi.PATH_JUMP | capi.PATH_SEGMENTED))
+        assert not (forced_path & (capi.PATH_JUMP | capi.PATH_SEGMENTED))
         assert forced_path & (capi.PATH_SEEK | capi.PATH_STAGED)
+    if env == 'XICSRT_PLASMA_STAGED' and (default_path & capi.PATH_PLASMA_SCOUT):
+        assert (forced_path & capi.PATH_STAGED) and not (forced_path & capi.PATH_PLASMA_SCOUT)
     if env == 'XICSRT_NO_STAGE_SPLIT' and (default_path & capi.PATH_STAGED):
         assert (default_path & capi.PATH_STAGE_SPLIT) and not (forced_path & capi.PATH_STAGE_SPLIT)
+    if env == 'XICSRT_NO_STAGE_SPLIT' and (default_path & capi.PATH_PLASMA_SCOUT):
+        # the staged kernels of a plasma scene: both switches together
+        monkeypatch.setenv('XICSRT_PLASMA_STAGED', '1')
+        dev2 = xrt.DeviceTrace(flat)
+        dev2.trace(seeds, g['number_of_iter'], keep_images=True)
+        meta, image = dev2.results()
+        forced_path = lib.xrt_last_path(1)
+        assert (forced_path & capi.PATH_STAGED) and not (forced_path & capi.PATH_STAGE_SPLIT)
     if env == 'XICSRT_STAGED_GAUSS' and (default_path & capi.PATH_GAUSS_PREPARED):
         assert (forced_path & capi.PATH_STAGED) and not (forced_path & capi.PATH_GAUSS_PREPARED)
     for nm in flat.names:

@@ -18,6 +18,7 @@ EXPORTS = (
     'xrt_timing_begin', 'xrt_timing_end', 'xrt_mt_jump_poly', 'xrt_check', 'xrt_make_image', 'xrt_last_path',
 )
 PATH_FUSED, PATH_STAGED, PATH_STAGE_SPLIT, PATH_JUMP, PATH_SEEK, PATH_SEGMENTED, PATH_GAUSS_PREPARED = 1, 2, 4, 8, 16, 32, 64
+PATH_PLASMA_SCOUT = 128
 
 _lib = None
 

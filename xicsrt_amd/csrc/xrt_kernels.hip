@@ -900,6 +900,10 @@ void xrt_seek_kernel(KStream* streams, KStream* heads, int n_runs, int n_arrays,
 #define XRT_JUMP_THREADS 1024
 #include "xrt_jump.inc"
 
+#define XRT_PLASMA_PART 1      // what the fused kernel needs of plasma sources (the scout kernel comes behind xrt_staged.inc)
+#include "xrt_plasma.inc"
+#undef XRT_PLASMA_PART
+
 // --------------------------------------------------------------------------
 // the propagation kernel
 // --------------------------------------------------------------------------
@@ -929,6 +933,7 @@ struct KArgs {
     // circular ray buffer in LDS: capacity in records and the Bragg batch (128 or 256 candidates)
     uint32_t qcap, bragg_batch;
     unsigned long long* progress;       // tiles done by all workgroups (null: no priority feedback)
+    KPlasmaRays plasma;                 // XRT_SRC_PLASMA: what xrt_plasma_scout_kernel left per run slot (run index = slot)
 };
 
 #ifndef XRT_WAVES_PER_EU
@@ -1038,9 +1043,12 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
         if (SEG) { run = unit / (uint32_t)args.n_seg; seg = unit - run * (uint32_t)args.n_seg; }
         if (run >= (uint32_t)args.n_runs) break;
         const bool counting = SEG && args.mode == 1;
+        // a plasma run has as many rays as its bundles drew (xrt_plasma_scout_kernel), N is the capacity
+        const bool plasma = FULL && !SEG && SRC.kind == XRT_SRC_PLASMA;
+        const int64_t N_run = plasma ? (int64_t)uni64((uint64_t)args.plasma.n_src[run]) : N;
         // ray range of this unit
         const int64_t ray_lo = SEG ? (int64_t)seg * args.seg_len : 0;
-        const int64_t ray_hi = SEG ? ((ray_lo + args.seg_len < N) ? ray_lo + args.seg_len : N) : N;
+        const int64_t ray_hi = SEG ? ((ray_lo + args.seg_len < N) ? ray_lo + args.seg_len : N) : N_run;
 
         // ---- load the positioned heads and the stream head ----------------
         // The source heads advance in lockstep (512 words per tile each), so they share one position:
@@ -1171,7 +1179,8 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
 
         // A point source (no spatial array in use: every offset is -0 + 0 u = 0) has one origin per run;
         // it and what the first element derives from it alone are evaluated here instead of per ray
-        const bool point = !EXT && (SRC.array_used & 7u) == 0u && SRC.kind != XRT_SRC_FOCUSED && SC.n_optics > 0;
+        const bool point = !EXT && (SRC.array_used & 7u) == 0u && SRC.kind != XRT_SRC_FOCUSED && SRC.kind != XRT_SRC_PLASMA &&
+                           SC.n_optics > 0;
         V3 O_run;
         PointPre pre0;
         O_run.x = O_run.y = O_run.z = 0.0;
@@ -1386,7 +1395,12 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
             if (have)
 #endif
             if (point) ray.o = O_run;
-            source_ray<FULL>(SRC, u, ray, point);
+            if constexpr (FULL && !SEG) {
+                if (plasma) {
+                    if (have) plasma_ray(SRC, args.plasma, (size_t)run, id, ray);
+                    else { ray.o.x = ray.o.y = ray.o.z = 0.0; ray.d = ray.o; ray.wl = 0.0; }
+                } else source_ray<FULL>(SRC, u, ray, point);
+            } else source_ray<FULL>(SRC, u, ray, point);
 #if XRT_ABLATE == 3
             have = have && (id == 0xffffffffu);
 #endif
@@ -1555,6 +1569,10 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
 
 #include "xrt_staged.inc"
 
+#define XRT_PLASMA_PART 2
+#include "xrt_plasma.inc"
+#undef XRT_PLASMA_PART
+
 
 #include "xrt_gauss.inc"
 
@@ -1670,6 +1688,7 @@ extern "C" int xrt_scene_check(const xrt_scene_t* sc)
 // workspace layout: [run counter 256 B][KScene][apertures][voigt tables][KState in][seeds][streams][heads]
 static int count_heads(const xrt_scene_t* sc)
 {
+    if (sc->source.kind == XRT_SRC_PLASMA) return 0;    // fused path: the draws come from the scout's stream dump
     int n = 2;      // the two angular arrays are always needed
     for (int i = 0; i < 3; i++) if (sc->source.size[i] != 0.0) n++;
     if (sc->source.wavelength_dist == XRT_WL_UNIFORM || sc->source.wavelength_dist == XRT_WL_VOIGT) n++;
@@ -1699,6 +1718,23 @@ static bool gauss_prepared(const xrt_source_t& s)
 {
     return s.wavelength_dist == XRT_WL_NORMAL && (s.intensity % 2) == 0 && s.intensity >= 2 * XRT_TILE &&
            !getenv("XICSRT_NO_JUMP") && !getenv("XICSRT_STAGED_GAUSS");
+}
+
+// Optics side of needs_staged: whole-array passes per mosaic layer, more than one Bragg element
+static bool optics_need_staged(const xrt_scene_t* sc)
+{
+    int n_bragg = 0;
+    for (int e = 0; e < sc->n_optics; e++) {
+        if (sc->optics[e].interact == XRT_INTERACT_MOSAIC) return true;
+        if (sc->optics[e].interact == XRT_INTERACT_CRYSTAL && (sc->optics[e].flags & XRT_F_CHECK_BRAGG)) n_bragg++;
+    }
+    return n_bragg > 1;
+}
+// A plasma scene whose optics the fused kernel can take: scout kernel + fused kernel (xrt_plasma.inc); only
+// xrt_trace_history (one run, history) still sends such a scene through the staged kernel.
+static bool plasma_fused(const xrt_scene_t* sc)
+{
+    return sc->source.kind == XRT_SRC_PLASMA && !optics_need_staged(sc) && !getenv("XICSRT_PLASMA_STAGED");
 }
 
 static bool needs_staged(const xrt_scene_t* sc)
@@ -1764,7 +1800,35 @@ static size_t staged_slot_bytes(const xrt_scene_t* sc)
 // source and optics run as separate launches over batches of up to 4 x 256 run slots
 static int staged_slots(const xrt_scene_t* sc, int n_runs)
 {
+    if (plasma_fused(sc)) n_runs = 1;      // the staged kernel only serves xrt_trace_history then
     return staged_slots_for(n_runs, staged_slot_bytes(sc), sc->source.kind == XRT_SRC_EXTERNAL ? 1 : 4);
+}
+// plasma on the fused path: per run slot the scout's bundle tables, ray -> bundle map, normal wavelengths and
+// the stream dump (every word of the source stage: 10-12 per ray, the Poisson trials, the rejected normal
+// candidates); as many slots as runs within the budget
+static size_t plasma_dump_words(const xrt_scene_t* sc)
+{
+    const size_t n = (size_t)(sc->source.intensity > 0 ? sc->source.intensity : 1);
+    const size_t nb = (size_t)(sc->source.bundle_count > 0 ? sc->source.bundle_count : 0);
+    return (16 * n + 86 * nb + 8192 + 63) / 64 * 64;
+}
+static size_t plasma_slot_bytes(const xrt_scene_t* sc)
+{
+    const size_t n = (size_t)(sc->source.intensity > 0 ? sc->source.intensity : 1);
+    const size_t nb = (size_t)(sc->source.bundle_count > 0 ? sc->source.bundle_count : 0);
+    return al256(nb * XRT_PB_ROWS * 8) + al256(nb * XRT_PP_ROWS * 8) + al256(n * 4) + al256(n * 8) + al256(plasma_dump_words(sc) * 4);
+}
+static int plasma_slots(const xrt_scene_t* sc, int n_runs)
+{
+    size_t s = XRT_ST_BUDGET / plasma_slot_bytes(sc);
+    if (s < 1) s = 1;
+    if ((size_t)n_runs < s) s = (size_t)(n_runs < 1 ? 1 : n_runs);
+    return (int)s;
+}
+static size_t plasma_ws_bytes(const xrt_scene_t* sc, int n_runs)
+{
+    if (!plasma_fused(sc)) return 0;
+    return al256((size_t)plasma_slots(sc, n_runs) * (plasma_slot_bytes(sc) + 8) + 256);
 }
 static size_t staged_bytes(const xrt_scene_t* sc, int n_runs)
 {
@@ -1841,11 +1905,15 @@ static size_t seg_bytes(const xrt_scene_t* sc, int n_runs)
     return b;
 }
 
+static size_t ws_off_plasma_rays(const xrt_scene_t* sc, int n_runs)
+{
+    return al256(ws_off_staged(sc, n_runs) + staged_bytes(sc, n_runs) + meshes_bytes(sc) + plasma_bytes(sc) + seg_bytes(sc, n_runs) + 256);
+}
 extern "C" size_t xrt_workspace_bytes(const xrt_scene_t* sc, int32_t n_runs)
 {
     if (!sc || n_runs < 0) return 0;
     if (n_runs < 1) n_runs = 1;
-    return ws_off_staged(sc, n_runs) + staged_bytes(sc, n_runs) + meshes_bytes(sc) + plasma_bytes(sc) + seg_bytes(sc, n_runs) + 256;
+    return ws_off_plasma_rays(sc, n_runs) + plasma_ws_bytes(sc, n_runs) + 256;
 }
 static size_t ws_off_seg(const xrt_scene_t* sc, int n_runs)
 {
@@ -1863,7 +1931,7 @@ static bool needs_ext(const xrt_scene_t* sc)
 static bool needs_full(const xrt_scene_t* sc)
 {
     const xrt_source_t& s = sc->source;
-    if (s.kind == XRT_SRC_FOCUSED || s.angular_dist != XRT_ANG_ISOTROPIC || s.wavelength_dist == XRT_WL_VOIGT) return true;
+    if (s.kind == XRT_SRC_FOCUSED || s.kind == XRT_SRC_PLASMA || s.angular_dist != XRT_ANG_ISOTROPIC || s.wavelength_dist == XRT_WL_VOIGT) return true;
     if (s.wavelength_dist == XRT_WL_NORMAL && s.has_velocity) return true;     // Doppler shift of a prepared wavelength
     for (int e = 0; e < sc->n_optics; e++) {
         const xrt_optic_t& o = sc->optics[e];
@@ -1966,6 +2034,7 @@ static void build_kscene(const xrt_scene_t* sc, char* ws, KScene* k)
     for (int i = 0; i < 3; i++) if (s.size[i] != 0.0) d.array_used |= 1u << i;
     d.array_used |= (1u << 3) | (1u << 4);
     if (wl_array) d.array_used |= 1u << 5;
+    if (s.kind == XRT_SRC_PLASMA) d.array_used = 0;     // no positioned heads: see xrt_plasma.inc
 
     k->n_optics = sc->n_optics;
     for (int e = 0; e < sc->n_optics; e++) {
@@ -2243,6 +2312,45 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
     KStream* streams = reinterpret_cast<KStream*>(ws + ws_off_streams(sc, n_runs));
     KStream* heads = reinterpret_cast<KStream*>(ws + ws_off_heads(sc, n_runs));
     const int64_t N = ks.src.n_rays;
+    if (plasma_fused(sc) && !hist && !force_staged) {
+        // ---- plasma source on the fused path: scout (one wave per run), then the fused kernel ---------------
+        g_paths |= XRT_PATH_FUSED | XRT_PATH_PLASMA_SCOUT;
+        const int slots = plasma_slots(sc, n_runs);
+        const size_t B = (size_t)(sc->source.bundle_count > 0 ? sc->source.bundle_count : 0), NN = (size_t)(N > 0 ? N : 1);
+        char* base = ws + ws_off_plasma_rays(sc, n_runs);
+        KScout ps;
+        memset(&ps, 0, sizeof(ps));
+        char* p = base;
+        ps.n_src = reinterpret_cast<long long*>(p);                     p += al256((size_t)slots * 8);
+        ps.btab = reinterpret_cast<double*>(p);                         p += (size_t)slots * al256(B * XRT_PB_ROWS * 8);
+        ps.bpos = reinterpret_cast<long long*>(p);                      p += (size_t)slots * al256(B * XRT_PP_ROWS * 8);
+        ps.ray_bundle = reinterpret_cast<uint32_t*>(p);                 p += (size_t)slots * al256(NN * 4);
+        ps.wl = reinterpret_cast<double*>(p);                           p += (size_t)slots * al256(NN * 8);
+        ps.dump = reinterpret_cast<uint32_t*>(p);
+        ps.dump_words = plasma_dump_words(sc);
+        // (slot strides: the arrays are indexed [slot][...] with the unpadded sizes; al256 only pads the regions)
+        ps.gauss_state = reinterpret_cast<KState*>(ws + ws_off_gauss(sc, n_runs));
+        ps.flags = reinterpret_cast<uint32_t*>(ws) + 16;
+        a.n_src_heads = 0;
+        a.run_counter = reinterpret_cast<uint32_t*>(ws);
+        a.progress = env_on("XICSRT_NO_PRIORITY_FEEDBACK") ? nullptr : reinterpret_cast<unsigned long long*>(ws + 32);
+        a.plasma.btab = ps.btab; a.plasma.bpos = ps.bpos; a.plasma.ray_bundle = ps.ray_bundle; a.plasma.wl = ps.wl;
+        a.plasma.dump = ps.dump; a.plasma.n_src = ps.n_src; a.plasma.dump_words = ps.dump_words;
+        const bool ext = needs_ext(sc);
+        const size_t lds = plan_queue(ks, 0, ext, false, &a);
+        for (int base_run = 0; base_run < n_runs; base_run += slots) {
+            const int nb = (n_runs - base_run) < slots ? (n_runs - base_run) : slots;
+            ps.run_base = base_run; ps.n_runs = nb;
+            hipLaunchKernelGGL(xrt_plasma_scout_kernel, dim3((nb + 3) / 4), dim3(256), 0, stream, device_scene(ws), streams, ps);
+            HIP_TRY(hipGetLastError());
+            a.streams = streams + base_run; a.heads = heads; a.n_runs = nb;
+            HIP_TRY(hipMemsetAsync(ws, 0, 64, stream));
+            const int st = ext ? launch_variant<false, 2>(device_scene(ws), a, nb, lds, stream)
+                               : launch_variant<false, 1>(device_scene(ws), a, nb, lds, stream);
+            if (st) return st;
+        }
+        return 0;
+    }
 #ifdef XRT_DEV_ONLY_LEAN
     if (needs_staged(sc) || force_staged) return fail(-3, "%s", "development build: lean kernel only");
 #else
