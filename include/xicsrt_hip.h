@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define XRT_ABI_VERSION 12
+#define XRT_ABI_VERSION 13
 
 #define XRT_MAX_OPTICS     16
 #define XRT_MAX_APERTURES  8
@@ -62,7 +62,8 @@ enum { XRT_SPATIAL_UNIFORM = 0, XRT_SPATIAL_GAUSSIAN = 1 };
 enum { XRT_ANG_ISOTROPIC = 0, XRT_ANG_ISOTROPIC_XY = 1, XRT_ANG_FLAT = 2, XRT_ANG_FLAT_XY = 3 };
 /* effective wavelength sampler after the reference's own case analysis
  * (_XicsrtSourceGeneric.py:295-367): CONST consumes no random numbers. */
-enum { XRT_WL_CONST = 0, XRT_WL_UNIFORM = 1, XRT_WL_NORMAL = 2, XRT_WL_VOIGT = 3 };
+enum { XRT_WL_CONST = 0, XRT_WL_UNIFORM = 1, XRT_WL_NORMAL = 2, XRT_WL_VOIGT = 3,
+       XRT_WL_VOIGT_BUNDLE = 4 /* internal: a plasma bundle with its own Voigt table (never in xrt_source_t) */ };
 
 /* Shape* classes (optics/_ShapePlane.py, _ShapeSphere.py, _ShapeCylinder.py, _ShapeTorus.py) */
 enum { XRT_SHAPE_PLANE = 0, XRT_SHAPE_SPHERE = 1, XRT_SHAPE_CYLINDER = 2, XRT_SHAPE_TORUS = 3,
@@ -142,6 +143,15 @@ typedef struct xrt_plasma {
                                 * volume_ratio = volume / (bundle_count * bundle_volume)      */
     double  mass_number, amu_kg, c_squared, ev_J;   /* per-bundle Doppler width, c_squared = c**2 (_XicsrtSourceGeneric.py:363-365) */
     xrt_bundle_filter_t filters[XRT_MAX_BUNDLE_FILTERS];
+    /* A temperature profile together with a natural line width (wavelength_dist = XRT_WL_VOIGT, voigt_n = 0 at
+     * the source level): every bundle samples its own Voigt profile, whose CDF table of 1000 points
+     * (tools/xicsrt_voigt.py:30-130, voigt_cdf_tab with the bundle's sigma) is built per bundle.  The
+     * Faddeeva function Re w(z) of that table (scipy.special.wofz in the reference) is evaluated with
+     * Weideman's rational approximation (SIAM J. Numer. Anal. 31 (1994) 1497): coefficients from the host. */
+    double  voigt_gamma;       /* linewidth * wavelength**2 / (4 pi c 1e10) (_XicsrtSourceGeneric.py:346); 0: unused */
+    double  weideman_L;
+    const double* weideman_a;  /* HOST pointer, n_weideman polynomial coefficients, highest power first */
+    int32_t n_weideman, pad2;
 } xrt_plasma_t;
 
 typedef struct xrt_source {

@@ -451,12 +451,68 @@ static double np_interp_zero(double x, const double* xp, const double* fp, int n
     return np_interp(x, xp, fp, n);
 }
 
+/* tools/xicsrt_voigt.py:30-106 voigt_cdf_tab(gamma, sigma) with the default gridsize 1000 and cutoff 1e-5:
+ * cdf_x = bounds[1:] and cdf, NumPy's element-wise expressions in their order, np.cumsum sequentially.
+ * wofz(z).real (scipy.special, Faddeeva function) is taken from Weideman's rational approximation (SIAM J.
+ * Numer. Anal. 31 (1994) 1497, coefficients from the host, see xrt_plasma_t): within 3e-16 of SciPy's
+ * values on the tables (tests/test_host.py).  Returns 0 when the reference would raise. */
+#define VOIGT_GRID 1000
+static double faddeeva_re(double u, double a, double L, const double* coef, int n)
+{
+    const double dr = L + a, di = -u, nr = L - a, ni = u;       /* L - i z, L + i z for z = u + i a */
+    const double den = dr * dr + di * di;
+    const double Zr = (nr * dr + ni * di) / den, Zi = (ni * dr - nr * di) / den;
+    double pr = coef[0], pi = 0.0;
+    for (int k = 1; k < n; k++) {
+        const double tr = pr * Zr - pi * Zi + coef[k];
+        pi = pr * Zi + pi * Zr;
+        pr = tr;
+    }
+    const double d2r = dr * dr - di * di, d2i = 2.0 * dr * di, den2 = d2r * d2r + d2i * d2i;
+    return 2.0 * (pr * d2r + pi * d2i) / den2 + 0.5641895835477563 * dr / den;
+}
+
+static int voigt_cdf_tab(double gamma, double sigma, const xrt_plasma_t* P, double* cdf_x, double* cdf)
+{
+    const double fraction = 0.5, cutoff = 1e-5;
+    const double gauss_hwfm = sqrt(2.0 * log(1.0 / fraction)) * sigma;
+    const double lorentz_hwfm = gamma * sqrt(1.0 / fraction - 1.0);
+    const double hwfm_max = sqrt(gauss_hwfm * gauss_hwfm + lorentz_hwfm * lorentz_hwfm);
+    const double min_spacing = hwfm_max / 5.0;
+    const double value = 100.0 / 2 * min_spacing;
+    const double lorentz_cutoff = gamma * sqrt(1.0 / cutoff - 1.0);
+    const double gauss_cutoff = sqrt(-1 * (sigma * sigma) * 2 * log(cutoff * sigma * sqrt(2 * 3.141592653589793)));
+    const double value_cutoff = lorentz_cutoff > gauss_cutoff ? lorentz_cutoff : gauss_cutoff;
+    const double base = exp(1.0 / 10 * log(value_cutoff / value));
+    const double step = (value - (-value)) / (double)VOIGT_GRID;
+    const double a_im = (gamma / sqrt(2.0)) / sigma, norm = sqrt(2 * 3.141592653589793);
+    double lo = 0.0, acc = 0.0, hi_cdf = 0.0;
+    int mid = 0;
+    for (int i = 0; i <= VOIGT_GRID; i++) {
+        const double b0 = (i == VOIGT_GRID) ? value : (double)i * step + (-value);
+        const double b = b0 * pow(base, fabs(b0 / value * 10));
+        if (i > 0) {
+            const double cx = (lo + b) / 2;
+            const double u = ((cx - 0.0) / sqrt(2.0)) / sigma;
+            const double y = faddeeva_re(u, a_im, P->weideman_L, P->weideman_a, P->n_weideman) / norm / sigma * 1.0;
+            const double ydx = y * (b - lo);
+            acc = (i == 1) ? ydx : acc + ydx;
+            cdf_x[i - 1] = b;
+            cdf[i - 1] = acc;
+            if (i == 1 || acc > hi_cdf) hi_cdf = acc;
+            mid += (acc > 0.25) && (acc < 0.75);
+        }
+        lo = b;
+    }
+    return !(mid < 3 || hi_cdf < 0.99);
+}
+
 /* What the reference's bundle pipeline assigns to the bundle centred at c (external frame):
  * bundle_filter (filters/_XicsrtBundleFilterSightline.py:31-56), bundle_generate
  * (sources/_XicsrtPlasmaToroidal.py:47-78 with tools/xicsrt_math.py:211-244), setup_bundle_spread
  * and the intensity of create_sources (sources/_XicsrtPlasmaGeneric.py:206-231, :301-319).
  * Fills `sb` (the bundle's focused source) and *lam; returns 0 when the bundle is masked out. */
-static int bundle_eval(const xrt_source_t* s, const double* c, xrt_source_t* sb, double* lam)
+static int bundle_eval(const xrt_source_t* s, const double* c, xrt_source_t* sb, double* lam, double* vtab)
 {
     const xrt_plasma_t* P = s->plasma;
     *sb = *s;
@@ -488,6 +544,18 @@ static int bundle_eval(const xrt_source_t* s, const double* c, xrt_source_t* sb,
                     sb->wavelength_dist = XRT_WL_NORMAL;
                     sb->wl_a = sqrt(temp / P->mass_number / P->amu_kg / P->c_squared * P->ev_J) * s->wavelength;
                 }
+            } else if (s->wavelength_dist == XRT_WL_VOIGT && P->voigt_gamma > 0.0) {
+                /* linewidth != 0: the bundle's own Voigt profile; a cold bundle gets 1 eV (:335-353) */
+                const double tv = (temp == 0.0) ? temp + 1.0 : temp;
+                const double sigma = sqrt(tv / P->mass_number / P->amu_kg / P->c_squared * P->ev_J) * s->wavelength;
+                if (!voigt_cdf_tab(P->voigt_gamma, sigma, P, vtab, vtab + VOIGT_GRID)) return -9;
+                sb->voigt_x = vtab; sb->voigt_cdf = vtab + VOIGT_GRID; sb->voigt_n = VOIGT_GRID;
+                double lo = vtab[VOIGT_GRID], hi = vtab[VOIGT_GRID];
+                for (int i = 1; i < VOIGT_GRID; i++) {
+                    if (vtab[VOIGT_GRID + i] < lo) lo = vtab[VOIGT_GRID + i];
+                    if (vtab[VOIGT_GRID + i] > hi) hi = vtab[VOIGT_GRID + i];
+                }
+                sb->wl_a = lo; sb->wl_b = hi - lo;         /* np.random.uniform(np.min(cdf), np.max(cdf), size) */
             }
         }
         if (P->n_emissivity > 0)
@@ -530,7 +598,8 @@ static int64_t generate_rays(const xrt_source_t* s, mt_t* mt, rays_t* r)
         return r->n;
     }
     const int64_t B = s->bundle_count;
-    double* off = malloc(sizeof(double) * 3 * (size_t)(B > 0 ? B : 1));
+    double* off = malloc(sizeof(double) * (3 * (size_t)(B > 0 ? B : 1) + 2 * VOIGT_GRID));
+    double* vtab = off + 3 * (size_t)(B > 0 ? B : 1);
     for (int k = 0; k < 3; k++) {
         double low = -1.0 * s->plasma_size[k] / 2.0, high = s->plasma_size[k] / 2.0;
         fill_uniform(mt, low, high - low, off + k * B, B);
@@ -545,7 +614,9 @@ static int64_t generate_rays(const xrt_source_t* s, mt_t* mt, rays_t* r)
         const xrt_source_t* sb = s;
         double lam = s->bundle_intensity;
         if (s->plasma) {
-            if (!bundle_eval(s, c, &sb_store, &lam)) continue;      /* masked bundles draw nothing (:288-289) */
+            const int ok = bundle_eval(s, c, &sb_store, &lam, vtab);
+            if (ok < 0) { free(off); return -9; }                    /* voigt_cdf_tab raised */
+            if (!ok) continue;                                       /* masked bundles draw nothing (:288-289) */
             sb = &sb_store;
         }
         if (s->use_poisson) nb = mt_poisson(mt, lam);

@@ -349,6 +349,12 @@ def build_cases():
     cfg = cfg_three(0, sph, source=dict(dat, filters=['sight'], spread=None, spread_radius=0.03), seed=66, runs=2, iters=2)
     cfg['filters'] = flt
     add('F_datafile_filter_counts', 'counts', cfg)
+    # a temperature profile together with a natural line width: one Voigt profile per bundle (the realistic
+    # W7-X / ITER line shape); the profile's zero-temperature tail exercises the reference's +1 eV rule
+    vgt = dict(dat, linewidth=1.0e14, wavelength_dist='voigt')
+    add('F_toroidal_voigt_trace', 'trace', cfg_three(0, sph, source=vgt, history=True, seed=70))
+    add('F_toroidal_voigt_counts', 'counts', cfg_three(0, dict(sph, rocking_fwhm=2e-3), source=dict(vgt, emissivity_scale=0.9),
+                                                       seed=71, runs=2, iters=2))
     add('F_spread_radius_trace', 'trace', cfg_three(0, sph, source=dict(box, spread=None, spread_radius=0.02,
                                                                        emissivity=6e12), history=True, seed=67))
     cfg = cfg_three(0, sph, source=dict(box, filters=['sight'], emissivity=2e13), history=True, seed=68)

@@ -155,9 +155,11 @@ def test_unsupported_scenes_fail_loudly():
     assert L.xrt_scene_check(flat.byref()) != 0
     assert b'2^29' in L.xrt_last_error()
     cfg, gold = helpers.load_golden('F_datafile_trace')
-    cfg['sources']['source'].update(linewidth=1e13)         # one Voigt table per bundle would be needed
-    with pytest.raises(NotImplementedError):
-        helpers.build(cfg)
+    cfg['sources']['source'].update(linewidth=1e13)         # one Voigt table per bundle: built on the device
+    config, elements, flat = helpers.build(cfg)
+    assert L.xrt_scene_check(flat.byref()) == 0
+    flat.struct.source.plasma.contents.n_weideman = 0       # ... from coefficients that must be there
+    assert L.xrt_scene_check(flat.byref()) != 0 and b'Weideman' in L.xrt_last_error()
     cfg, gold = helpers.load_golden('C_sphere_trace')       # ray filters on a plain source
     cfg['filters'] = {'sight': {'class_name': 'XicsrtBundleFilterSightline', 'radius': 0.1}}
     cfg['sources']['source']['filters'] = ['sight']
@@ -281,3 +283,39 @@ def test_jump_polynomials_satisfy_the_generator_recurrence():
             for j in bits:
                 acc ^= s[n + j]
             assert acc == s[n + J], (J, n)
+
+
+def test_weideman_faddeeva_reproduces_the_voigt_tables_of_scipy():
+    """The per-bundle Voigt tables are built on the device with Weideman's approximation of Re w(z); with the
+    coefficients the host hands over, the table of tools/xicsrt_voigt.py (restated here with scipy.special.wofz)
+    comes out to 1e-15, far inside the parity tolerance on wavelengths."""
+    from scipy.special import wofz
+    from xicsrt_amd import scene as xscene
+
+    big_l, coeff = xscene.weideman_coefficients(40)
+
+    def rational(z):
+        zz = (big_l + 1j * z) / (big_l - 1j * z)
+        return 2 * np.polyval(coeff, zz) / (big_l - 1j * z) ** 2 + (1 / np.sqrt(np.pi)) / (big_l - 1j * z)
+
+    def table(gamma, sigma, w):
+        value = 100 / 2 * np.sqrt((np.sqrt(2.0 * np.log(2.0)) * sigma) ** 2 + gamma ** 2) / 5.0
+        cut = max(gamma * np.sqrt(1.0 / 1e-5 - 1.0), np.sqrt(-1 * sigma ** 2 * 2 * np.log(1e-5 * sigma * np.sqrt(2 * np.pi))))
+        base = np.exp(1 / 10 * np.log(cut / value))
+        bounds = np.linspace(-value, value, 1001)
+        bounds = bounds * base ** np.abs(bounds / value * 10)
+        x = (bounds[:-1] + bounds[1:]) / 2
+        y = w((x + 1j * gamma) / np.sqrt(2) / sigma).real / np.sqrt(2 * np.pi) / sigma
+        return np.cumsum(y * (bounds[1:] - bounds[:-1]))
+
+    for gamma, sigma in ((4.14e-5, 6.47e-4), (4.14e-6, 2.05e-4), (4.14e-4, 1.12e-3), (4.14e-7, 2.05e-5), (1e-3, 1e-5)):
+        a, b = table(gamma, sigma, wofz), table(gamma, sigma, rational)
+        assert a[-1] > 0.99 and np.max(np.abs(a - b)) < 2e-15
+
+
+def test_plasma_with_temperature_profile_and_linewidth_flattens():
+    """One Voigt profile per bundle: the scene carries gamma and the approximation's coefficients."""
+    cfg, _ = helpers.load_golden('F_toroidal_voigt_trace')
+    config, elements, flat = helpers.build(cfg)
+    pl = flat.struct.source.plasma.contents
+    assert pl.n_temperature > 0 and pl.voigt_gamma > 0.0 and pl.n_weideman == 40 and pl.weideman_L > 0.0

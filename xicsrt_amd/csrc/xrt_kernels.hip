@@ -64,6 +64,9 @@ struct KPlasma {             // device copy of xrt_plasma_t (table pointers are 
     double  time_resolution, bundle_volume, four_pi, volume_ratio;
     double  mass_number, amu_kg, c_squared, ev_J;
     xrt_bundle_filter_t filters[XRT_MAX_BUNDLE_FILTERS];
+    double  voigt_gamma, weideman_L;    // per-bundle Voigt profiles (see xrt_plasma_t)
+    const double* weideman_a;           // device
+    int32_t n_weideman, pad2;
 };
 
 struct KSource {
@@ -1634,8 +1637,9 @@ extern "C" int xrt_scene_check(const xrt_scene_t* sc)
             return fail(-2, "%s", "plasma profile tables missing");
         if ((P->n_emissivity > 0 || P->n_temperature > 0) && P->geometry != XRT_PLASMA_TOROIDAL)
             return fail(-2, "%s", "plasma profiles need a flux geometry");
-        if (P->n_temperature > 0 && sc->source.wavelength_dist == XRT_WL_VOIGT)
-            return fail(-3, "%s", "a temperature profile with a natural linewidth is not implemented on the device path");
+        if (P->n_temperature > 0 && sc->source.wavelength_dist == XRT_WL_VOIGT &&
+            (!(P->voigt_gamma > 0.0) || P->n_weideman < 8 || P->n_weideman > 64 || !P->weideman_a))
+            return fail(-2, "%s", "a temperature profile with a natural linewidth needs voigt_gamma and the Weideman coefficients");
     }
     if (sc->n_optics < 0 || sc->n_optics > XRT_DEV_MAX_OPTICS)
         return fail(-2, "%s", "device path supports at most 16 optics (XRT_MAX_OPTICS)");
@@ -1788,14 +1792,16 @@ static size_t plasma_bytes(const xrt_scene_t* sc)
     const xrt_plasma_t* P = sc->source.plasma;
     if (!P) return 0;
     return al256(sizeof(KPlasma)) + 2 * al256(sizeof(double) * (size_t)(P->n_emissivity > 0 ? P->n_emissivity : 1))
-                                  + 2 * al256(sizeof(double) * (size_t)(P->n_temperature > 0 ? P->n_temperature : 1));
+                                  + 2 * al256(sizeof(double) * (size_t)(P->n_temperature > 0 ? P->n_temperature : 1))
+                                  + al256(sizeof(double) * (size_t)(P->n_weideman > 0 ? P->n_weideman : 1));
 }
 
 static size_t staged_slot_bytes(const xrt_scene_t* sc)
 {
     const size_t n = (size_t)(sc->source.intensity > 0 ? sc->source.intensity : 1);
     const size_t nb = (size_t)(sc->source.bundle_count > 0 ? sc->source.bundle_count : 0);
-    return n * (XRT_ST_ARRAYS * sizeof(double) + 2 * sizeof(uint32_t)) + nb * XRT_ST_BUNDLE_ROWS * sizeof(double) + 16;
+    const size_t voigt = (sc->source.plasma && sc->source.plasma->voigt_gamma > 0.0) ? 2 * XRT_VOIGT_GRID * sizeof(double) : 0;
+    return n * (XRT_ST_ARRAYS * sizeof(double) + 2 * sizeof(uint32_t)) + nb * XRT_ST_BUNDLE_ROWS * sizeof(double) + voigt + 16;
 }
 // source and optics run as separate launches over batches of up to 4 x 256 run slots
 static int staged_slots(const xrt_scene_t* sc, int n_runs)
@@ -2212,6 +2218,8 @@ static int upload_plasma(const xrt_scene_t* sc, char* ws, int n_runs, KScene* ks
     k.emissivity_val = put(P->emissivity_val, P->n_emissivity);
     k.temperature_rho = put(P->temperature_rho, P->n_temperature);
     k.temperature_val = put(P->temperature_val, P->n_temperature);
+    k.voigt_gamma = P->voigt_gamma; k.weideman_L = P->weideman_L; k.n_weideman = P->n_weideman;
+    k.weideman_a = put(P->weideman_a, P->n_weideman);
     HIP_TRY(hipMemcpyAsync(base, &k, sizeof(KPlasma), hipMemcpyHostToDevice, stream));
     ks->src.plasma = reinterpret_cast<const KPlasma*>(base);
     return 0;
@@ -2341,7 +2349,10 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
         for (int base_run = 0; base_run < n_runs; base_run += slots) {
             const int nb = (n_runs - base_run) < slots ? (n_runs - base_run) : slots;
             ps.run_base = base_run; ps.n_runs = nb;
-            hipLaunchKernelGGL(xrt_plasma_scout_kernel, dim3((nb + 3) / 4), dim3(256), 0, stream, device_scene(ws), streams, ps);
+            const size_t scout_lds = (sc->source.plasma && sc->source.plasma->voigt_gamma > 0.0) ? 4 * 2 * XRT_VOIGT_GRID * sizeof(double) : 0;
+            if (scout_lds)
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(xrt_plasma_scout_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scout_lds));
+            hipLaunchKernelGGL(xrt_plasma_scout_kernel, dim3((nb + 3) / 4), dim3(256), scout_lds, stream, device_scene(ws), streams, ps);
             HIP_TRY(hipGetLastError());
             a.streams = streams + base_run; a.heads = heads; a.n_runs = nb;
             HIP_TRY(hipMemsetAsync(ws, 0, 64, stream));
@@ -2365,6 +2376,8 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
         g.aux = g.ids + (size_t)slots * (size_t)N;
         g.bundle_off = reinterpret_cast<double*>(base + (size_t)slots * (size_t)N * (XRT_ST_ARRAYS * sizeof(double) + 2 * sizeof(uint32_t)));
         g.flags = reinterpret_cast<uint32_t*>(ws) + 16;        // status word in the 256-byte workspace header
+        if (sc->source.plasma && sc->source.plasma->voigt_gamma > 0.0)      // behind the bundle tables and the per-slot counts
+            g.voigt_tab = g.bundle_off + (size_t)slots * XRT_ST_BUNDLE_ROWS * (size_t)(sc->source.bundle_count > 0 ? sc->source.bundle_count : 0) + 2 * (size_t)slots;
         g.gauss_state = reinterpret_cast<KState*>(ws + ws_off_gauss(sc, n_runs));
         for (int i = 0; i < 9; i++) g.spatial_A[i] = sc->source.spatial_A[i];
         g.spatial_gaussian = sc->source.spatial_dist == XRT_SPATIAL_GAUSSIAN;
@@ -2747,6 +2760,8 @@ extern "C" int xrt_check(void* workspace, void* stream_)
         return fail(-7, "%s", "intensity of less than one encountered. Turn on poisson statistics.");
     if (flags & 4u)
         return fail(-8, "%s", "Gaussian wavelength sampler ran out of provisioned candidates (a > 8 sigma event)");
+    if (flags & 8u)
+        return fail(-9, "%s", "Voight CDF calculation does not have enough resolution or its domain is too small.");
     if (flags & 1u)
         return fail(-6, "%s", "plasma source produced more rays than the declared capacity (Poisson tail): results are truncated");
     return 0;
