@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define XRT_ABI_VERSION 13
+#define XRT_ABI_VERSION 14
 
 #define XRT_MAX_OPTICS     16
 #define XRT_MAX_APERTURES  8
@@ -358,6 +358,25 @@ int xrt_make_image(const xrt_optic_t* optic, int64_t n, const double* rays, cons
  * _XicsrtSourceGeneric.py:193-194); -8 the candidate reserve of the Gaussian wavelength sampler was
  * exhausted (a > 8 sigma event).  0 = clean. */
 int xrt_check(void* workspace, void* stream);
+
+/* TraceObject.intersect / check_bounds / interact as separate calls on a caller's ray array
+ * (optics/_TraceObject.py:157-180 `trace`: xloc, norm, mask = intersect(rays); mask = check_bounds(xloc, mask);
+ * rays = interact(rays, xloc, norm, mask)).  Analytic shapes (Shape{Plane,Sphere,Cylinder,Torus}.intersect,
+ * optics/_Shape*.py); all pointers DEVICE, rays component-major [8][n] as xrt_source_t.ext_rays, xloc and norm
+ * [3][n], masks one byte per ray.  Asynchronous on `stream`.
+ *   xrt_optic_intersect     rays with mask_in: intersection point and surface normal (NaN where there is none),
+ *                           mask_out = mask_in & has-intersection
+ *   xrt_optic_check_bounds  mask &= inside xsize/ysize/zsize and the aperture list (_TraceObject.py:180-232)
+ *   xrt_optic_interact      origin <- xloc for EVERY ray (_InteractMirror.py:38), rays with mask: mirror reflection
+ *                           (_InteractMirror.py:29-42) or, for a crystal with check_bragg, first the rocking-curve
+ *                           test p >= test[i] (_InteractCrystal.py:96-196; `test` = the uniform deviates the
+ *                           reference draws for the live rays, scattered to ray positions by the caller); mask out.
+ *                           Mosaic crystals (whole-array draws per layer) are refused: use xrt_trace_history. */
+int xrt_optic_intersect(const xrt_optic_t* optic, int64_t n, const double* rays, const uint8_t* mask_in,
+                        double* xloc, double* norm, uint8_t* mask_out, void* stream);
+int xrt_optic_check_bounds(const xrt_optic_t* optic, int64_t n, const double* xloc, uint8_t* mask, void* stream);
+int xrt_optic_interact(const xrt_optic_t* optic, int64_t n, double* rays, const double* xloc, const double* norm,
+                       uint8_t* mask, const double* test, void* stream);
 
 /* Diagnostics: the device routes taken by this thread's xrt_trace / xrt_trace_history calls since the last
  * call with reset != 0 (bit set below).  The routes are picked per scene; the environment switches

@@ -389,6 +389,14 @@ def build_cases():
     # --- object-level API: generate_rays / trace_global / make_image on a caller's ray array ----
     add('O_object_sphere', 'object', cfg_three(4000, dict(sph, rocking_fwhm=2e-3), seed=91))
     add('O_object_mirror_local', 'object', cfg_three(3000, dict(mir, trace_local=True), seed=92))
+    # the three steps of TraceObject.trace as separate calls
+    add('O_steps_sphere', 'steps', cfg_three(3000, dict(sph, rocking_fwhm=2e-3), seed=93))
+    add('O_steps_mirror_aperture', 'steps', cfg_three(3000, dict(mir, aperture=[{'shape': 'circle', 'size': [0.08]},
+                                                                               {'shape': 'square', 'size': [0.05], 'logic': 'not'}]), seed=94))
+    add('O_steps_cylinder_step', 'steps', cfg_three(3000, _crystal('XicsrtOpticCylindricalCrystal', radius=1.0,
+                                                                   **dict(_BRAGG, rocking_type='step', rocking_fwhm=5e-3)), seed=95))
+    add('O_steps_torus', 'steps', cfg_three(3000, _crystal('XicsrtOpticToroidalCrystal', radius_major=1.0, radius_minor=0.5,
+                                                           **dict(_BRAGG, check_bragg=False)), seed=96))
     add('O_object_torus', 'object', cfg_three(2000, _crystal('XicsrtOpticToroidalCrystal', radius_major=1.0, radius_minor=0.5,
                                                              **dict(_BRAGG, rocking_fwhm=5e-3)), seed=93))
 
@@ -622,7 +630,7 @@ def main(argv):
         kind, cfg = cases[name]
         try:
             out = {'trace': run_trace, 'counts': run_counts, 'history': run_history, 'mesh': run_mesh_tables,
-                   'object': run_object}[kind](cfg)
+                   'object': run_object, 'steps': run_steps}[kind](cfg)
         except Exception as e:  # reference raised: record that, it is part of the contract
             print('%-32s REFERENCE RAISED %s: %s' % (name, type(e).__name__, e))
             continue
@@ -656,6 +664,30 @@ def run_object(cfg):
         out['out/' + k] = np.array(rays[k])
     img = crystal.make_image(rays)
     out['image'] = img.astype(np.int64)
+    out['next_double'] = np.float64(np.random.random_sample())
+    return out
+
+
+def run_steps(cfg):
+    """Object-level API, step by step: rays from source.generate_rays(), some switched off, then the crystal's
+    intersect -> check_bounds -> interact (optics/_TraceObject.py:157-172), everything recorded after each step."""
+    cfg = _ref_cfg(cfg)
+    np.random.seed(cfg['general']['random_seed'])
+    source = xicsrt.get_element(cfg, 'source')
+    crystal = xicsrt.get_element(cfg, 'crystal')
+    rays = source.generate_rays()
+    rays['mask'][::7] = False
+    out = {'names': np.array(['source', 'crystal'])}
+    for k in ('origin', 'direction', 'wavelength', 'mask'):
+        out['in/' + k] = np.array(rays[k])
+    xloc, norm, mask = crystal.intersect(rays)
+    out['intersect/xloc'] = np.array(xloc); out['intersect/norm'] = np.array(norm); out['intersect/mask'] = np.array(mask)
+    out['intersect/rays_mask'] = np.array(rays['mask'])
+    mask = crystal.check_bounds(xloc, mask)
+    out['bounds/mask'] = np.array(mask)
+    rays = crystal.interact(rays, xloc, norm, mask)
+    for k in ('origin', 'direction', 'wavelength', 'mask'):
+        out['out/' + k] = np.array(rays[k])
     out['next_double'] = np.float64(np.random.random_sample())
     return out
 

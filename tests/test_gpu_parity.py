@@ -221,6 +221,48 @@ def test_object_level_api_matches_reference(name):
     assert np.random.random_sample() == float(gold['next_double'])
 
 
+def _close(h, g, what):
+    h, g = np.asarray(h), np.asarray(g)
+    assert np.array_equal(np.isnan(h), np.isnan(g)), 'NaN pattern of ' + what
+    ok = ~np.isnan(g)
+    if ok.any():
+        assert np.max(np.abs(h[ok] - g[ok])) <= FLOAT_RTOL * max(np.max(np.abs(g[ok])), 1e-300), what
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', helpers.golden_names('steps'))
+def test_intersect_check_bounds_interact_as_separate_calls(name):
+    """TraceObject.trace's three steps (optics/_TraceObject.py:157-172) one by one on a caller's rays: what each
+    returns, what it leaves in rays['mask'], and where the global np.random stream ends."""
+    import xicsrt_amd
+    cfg, gold = helpers.load_golden(name)
+    np.random.seed(cfg['general']['random_seed'])
+    source = xicsrt_amd.get_element(cfg, 'source')
+    crystal = xicsrt_amd.get_element(cfg, 'crystal')
+    rays = source.generate_rays()
+    rays['mask'][::7] = False
+    assert np.array_equal(rays['mask'], gold['in/mask'])
+    xloc, norm, mask = crystal.intersect(rays)
+    assert mask is rays['mask']                                  # the analytic shapes update rays['mask'] in place
+    assert np.array_equal(mask, gold['intersect/mask']) and np.array_equal(rays['mask'], gold['intersect/rays_mask'])
+    _close(xloc, gold['intersect/xloc'], 'xloc')
+    _close(norm, gold['intersect/norm'], 'norm')
+    mask = crystal.check_bounds(xloc, mask)
+    assert np.array_equal(mask, gold['bounds/mask'])
+    rays = crystal.interact(rays, xloc, norm, mask)
+    assert np.array_equal(rays['mask'], gold['out/mask'])
+    for key in ('origin', 'direction', 'wavelength'):
+        _close(rays[key], gold['out/' + key], key)
+    assert np.random.random_sample() == float(gold['next_double'])
+    # trace() = the three steps
+    np.random.seed(cfg['general']['random_seed'])
+    rays2 = source.generate_rays()
+    rays2['mask'][::7] = False
+    rays2 = crystal.trace(rays2)
+    assert np.array_equal(rays2['mask'], gold['out/mask'])
+    _close(rays2['direction'], gold['out/direction'], 'direction via trace()')
+
+
 @pytest.mark.gpu
 def test_integrated_test_00_photon_accounting():
     """The reference's own assertion (testing/integrated_test_00.ipynb): a 1 cm^3 plasma cube of emissivity

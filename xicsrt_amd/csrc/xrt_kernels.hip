@@ -1993,6 +1993,27 @@ static void bragg_screen(const xrt_source_t& src, KOptic& q)
     q.scr_ok = 1;
 }
 
+// the device form of one optic (table pointers are set by the caller)
+static void fill_koptic(const xrt_optic_t& o, KOptic& q)
+{
+    memset(&q, 0, sizeof(q));
+    q.shape = o.shape; q.interact = o.interact; q.flags = o.flags; q.rocking_type = o.rocking_type;
+    for (int i = 0; i < 3; i++) { q.origin[i] = o.origin[i]; q.half_size[i] = o.half_size[i]; q.center[i] = o.center[i]; }
+    for (int i = 0; i < 9; i++) q.R[i] = o.orientation[i];
+    q.radius = o.radius; q.radius2 = o.radius2;
+    q.torus_major = o.torus_major; q.torus_root = o.torus_root;
+    for (int i = 0; i < 5; i++) q.torus_k[i] = o.torus_k[i];
+    q.two_d = o.two_d; q.reflectivity = o.reflectivity; q.half_fwhm = o.rocking_half_fwhm;
+    q.two_sigma2 = o.rocking_2sigma2; q.half_pi = o.half_pi;
+    q.mosaic_depth = o.mosaic_depth; q.mosaic_has_cutoff = o.mosaic_has_cutoff;
+    q.mosaic_cutoff_angle = o.mosaic_cutoff_angle;
+    for (int i = 0; i < 4; i++) q.mosaic_A[i] = o.mosaic_A[i];
+    q.pixel_size = o.pixel_size; q.pixel_xoff = o.pixel_xoff; q.pixel_yoff = o.pixel_yoff;
+    q.pixel_nx = o.pixel_nx; q.pixel_ny = o.pixel_ny; q.image_offset = o.image_offset;
+    q.n_apertures = o.n_apertures;
+    q.scr_ptail = INFINITY;
+}
+
 static void build_kscene(const xrt_scene_t* sc, char* ws, KScene* k)
 {
     memset(k, 0, sizeof(*k));
@@ -2044,22 +2065,8 @@ static void build_kscene(const xrt_scene_t* sc, char* ws, KScene* k)
 
     k->n_optics = sc->n_optics;
     for (int e = 0; e < sc->n_optics; e++) {
-        const xrt_optic_t& o = sc->optics[e];
         KOptic& q = k->opt[e];
-        q.shape = o.shape; q.interact = o.interact; q.flags = o.flags; q.rocking_type = o.rocking_type;
-        for (int i = 0; i < 3; i++) { q.origin[i] = o.origin[i]; q.half_size[i] = o.half_size[i]; q.center[i] = o.center[i]; }
-        for (int i = 0; i < 9; i++) q.R[i] = o.orientation[i];
-        q.radius = o.radius; q.radius2 = o.radius2;
-        q.torus_major = o.torus_major; q.torus_root = o.torus_root;
-        for (int i = 0; i < 5; i++) q.torus_k[i] = o.torus_k[i];
-        q.two_d = o.two_d; q.reflectivity = o.reflectivity; q.half_fwhm = o.rocking_half_fwhm;
-        q.two_sigma2 = o.rocking_2sigma2; q.half_pi = o.half_pi;
-        q.mosaic_depth = o.mosaic_depth; q.mosaic_has_cutoff = o.mosaic_has_cutoff;
-        q.mosaic_cutoff_angle = o.mosaic_cutoff_angle;
-        for (int i = 0; i < 4; i++) q.mosaic_A[i] = o.mosaic_A[i];
-        q.pixel_size = o.pixel_size; q.pixel_xoff = o.pixel_xoff; q.pixel_yoff = o.pixel_yoff;
-        q.pixel_nx = o.pixel_nx; q.pixel_ny = o.pixel_ny; q.image_offset = o.image_offset;
-        q.n_apertures = o.n_apertures;
+        fill_koptic(sc->optics[e], q);
         q.apertures = reinterpret_cast<const xrt_aperture_t*>(ws + ws_off_apertures()) + (size_t)e * XRT_MAX_APERTURES;
         bragg_screen(s, q);
     }
@@ -2738,6 +2745,130 @@ extern "C" int xrt_make_image(const xrt_optic_t* optic, int64_t n, const double*
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     hipLaunchKernelGGL(xrt_image_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, q, n, rays, mask,
                        reinterpret_cast<unsigned long long*>(images));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---- TraceObject.intersect / check_bounds / interact as separate calls (optics/_TraceObject.py:157-180) --------
+// One optic, a caller's ray array (device, component-major [8][n] as xrt_source_t.ext_rays); xloc and norm
+// are [3][n].  The same device functions as in the propagation kernels, one ray per thread.
+struct KStep { KOptic op; xrt_aperture_t ap[XRT_MAX_APERTURES]; };
+
+__global__ void xrt_step_intersect_kernel(const KStep a, int64_t n, const double* rays, const uint8_t* mask_in,
+                                          double* xloc, double* norm, uint8_t* mask_out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    KOptic op = a.op;
+    op.apertures = a.ap;
+    const double nan = __builtin_nan("");
+    V3 X, nr;
+    X.x = X.y = X.z = nan; nr = X;
+    if (op.shape == XRT_SHAPE_TORUS) nr.x = nr.y = nr.z = 0.0;      // ShapeTorus.intersect_normal starts from zeros (:196)
+    bool m = mask_in[i] != 0;
+    if (m) {
+        Ray ray;
+        ray.o.x = rays[0 * n + i]; ray.o.y = rays[1 * n + i]; ray.o.z = rays[2 * n + i];
+        ray.d.x = rays[3 * n + i]; ray.d.y = rays[4 * n + i]; ray.d.z = rays[5 * n + i];
+        ray.wl = rays[6 * n + i];
+        V3 P;
+        m = intersect_point<true>(op, ray, P, false, PointPre());
+        if (m) { X = P; nr = surface_normal<true>(op, P); }
+    }
+    xloc[0 * n + i] = X.x; xloc[1 * n + i] = X.y; xloc[2 * n + i] = X.z;
+    norm[0 * n + i] = nr.x; norm[1 * n + i] = nr.y; norm[2 * n + i] = nr.z;
+    mask_out[i] = m ? 1 : 0;
+}
+
+__global__ void xrt_step_bounds_kernel(const KStep a, int64_t n, const double* xloc, uint8_t* mask)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !mask[i]) return;
+    KOptic op = a.op;
+    op.apertures = a.ap;
+    V3 X; X.x = xloc[0 * n + i]; X.y = xloc[1 * n + i]; X.z = xloc[2 * n + i];
+    if (!check_bounds<true>(op, X)) mask[i] = 0;
+}
+
+__global__ void xrt_step_interact_kernel(const KStep a, int64_t n, double* rays, const double* xloc, const double* norm,
+                                         uint8_t* mask, const double* test)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const KOptic& op = a.op;
+    // InteractObject / InteractMirror.reflect_vectors (optics/_InteractMirror.py:29-42): O[:] = xloc[:] for every ray
+    rays[0 * n + i] = xloc[0 * n + i]; rays[1 * n + i] = xloc[1 * n + i]; rays[2 * n + i] = xloc[2 * n + i];
+    bool m = mask[i] != 0;
+    if (m && op.interact != XRT_INTERACT_NONE) {
+        Ray ray;
+        ray.d.x = rays[3 * n + i]; ray.d.y = rays[4 * n + i]; ray.d.z = rays[5 * n + i];
+        ray.wl = rays[6 * n + i];
+        V3 nr; nr.x = norm[0 * n + i]; nr.y = norm[1 * n + i]; nr.z = norm[2 * n + i];
+        if (op.interact == XRT_INTERACT_CRYSTAL && (op.flags & XRT_F_CHECK_BRAGG))
+            m = bragg_accept(op, ray, nr, 0.0 + (1.0 - 0.0) * test[i], false, 0.0);      // InteractCrystal.angle_check (:126-145)
+        if (m) {
+            const double dt = dot_e(ray.d, nr);
+            rays[3 * n + i] = ray.d.x - 2.0 * (dt * nr.x);
+            rays[4 * n + i] = ray.d.y - 2.0 * (dt * nr.y);
+            rays[5 * n + i] = ray.d.z - 2.0 * (dt * nr.z);
+        }
+    }
+    mask[i] = m ? 1 : 0;
+}
+
+static int make_step(const xrt_optic_t* optic, KStep* k)
+{
+    if (!optic) return fail(-1, "%s", "NULL argument");
+    if (optic->shape < XRT_SHAPE_PLANE || optic->shape > XRT_SHAPE_TORUS)
+        return fail(-3, "%s", "step-wise calls are implemented for the analytic shapes (plane, sphere, cylinder, torus)");
+    if (optic->n_apertures < 0 || optic->n_apertures > XRT_MAX_APERTURES) return fail(-2, "%s", "bad aperture count");
+    fill_koptic(*optic, k->op);
+    memset(k->ap, 0, sizeof(k->ap));
+    for (int i = 0; i < optic->n_apertures; i++) k->ap[i] = optic->apertures[i];
+    return 0;
+}
+
+extern "C" int xrt_optic_intersect(const xrt_optic_t* optic, int64_t n, const double* rays, const uint8_t* mask_in,
+                                   double* xloc, double* norm, uint8_t* mask_out, void* stream_)
+{
+    static thread_local KStep k;
+    int st = make_step(optic, &k);
+    if (st) return st;
+    if (n <= 0) return 0;
+    if (!rays || !mask_in || !xloc || !norm || !mask_out) return fail(-1, "%s", "NULL argument");
+    hipLaunchKernelGGL(xrt_step_intersect_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_),
+                       k, n, rays, mask_in, xloc, norm, mask_out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int xrt_optic_check_bounds(const xrt_optic_t* optic, int64_t n, const double* xloc, uint8_t* mask, void* stream_)
+{
+    static thread_local KStep k;
+    int st = make_step(optic, &k);
+    if (st) return st;
+    if (n <= 0) return 0;
+    if (!xloc || !mask) return fail(-1, "%s", "NULL argument");
+    hipLaunchKernelGGL(xrt_step_bounds_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_),
+                       k, n, xloc, mask);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int xrt_optic_interact(const xrt_optic_t* optic, int64_t n, double* rays, const double* xloc, const double* norm,
+                                  uint8_t* mask, const double* test, void* stream_)
+{
+    static thread_local KStep k;
+    int st = make_step(optic, &k);
+    if (st) return st;
+    if (optic->interact == XRT_INTERACT_MOSAIC)
+        return fail(-3, "%s", "the mosaic interaction draws whole arrays per layer: use trace_global()");
+    if (n <= 0) return 0;
+    if (!rays || !xloc || !norm || !mask) return fail(-1, "%s", "NULL argument");
+    if (optic->interact == XRT_INTERACT_CRYSTAL && (optic->flags & XRT_F_CHECK_BRAGG) && !test)
+        return fail(-1, "%s", "a Bragg test needs one uniform deviate per ray");
+    hipLaunchKernelGGL(xrt_step_interact_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_),
+                       k, n, rays, xloc, norm, mask, test);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -77,19 +77,38 @@ class TraceObject(GeometryObject):
         return _rt.trace_optic_object(self, rays)
 
     def trace(self, rays):
-        if self.param['trace_local']:
-            raise NotImplementedError('trace() in local coordinates is only available through trace_global().')
-        return self.trace_global(rays)
+        """intersect -> check_bounds -> interact in the frame the rays are given in (optics/_TraceObject.py:157-172);
+        meshes and mosaic crystals, whose steps are not separate device calls, go through trace_global()."""
+        if self.shape_kind == 'mesh' or getattr(self, 'interact_kind', None) == 'mosaic':
+            if self.param['trace_local']:
+                raise NotImplementedError('trace() in local coordinates is only available through trace_global().')
+            return self.trace_global(rays)
+        xloc, norm, mask = self.intersect(rays)
+        mask = self.check_bounds(xloc, mask)
+        return self.interact(rays, xloc, norm, mask)
 
     def make_image(self, rays):
         from .. import xicsrt_raytrace as _rt
         return _rt.image_of_optic_object(self, rays)
 
-    def intersect(self, rays):
-        raise NotImplementedError(
-            'intersect/check_bounds/interact are fused in the device kernel; use trace_global().')
+    # The three steps of trace() as separate device calls (analytic shapes; see include/xicsrt_hip.h).
 
-    check_bounds = interact = intersect
+    def intersect(self, rays):
+        """(xloc, norm, mask): intersection points and surface normals (NaN where there is none); like the
+        reference's analytic shapes the returned mask IS rays['mask'], updated in place."""
+        from .. import xicsrt_raytrace as _rt
+        return _rt.optic_intersect(self, rays)
+
+    def check_bounds(self, X, mask):
+        """mask &= inside the size limits and the aperture list; updated in place and returned."""
+        from .. import xicsrt_raytrace as _rt
+        return _rt.optic_check_bounds(self, X, mask)
+
+    def interact(self, rays, xloc, norm, mask=None):
+        """Origins <- xloc, reflection / Bragg test of the rays in `mask`; a Bragg test draws
+        np.random.uniform(0, 1, n_live) from the global legacy stream, as the reference does."""
+        from .. import xicsrt_raytrace as _rt
+        return _rt.optic_interact(self, rays, xloc, norm, mask)
 
 
 # ---- shapes ---------------------------------------------------------------

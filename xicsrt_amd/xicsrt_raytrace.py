@@ -801,3 +801,86 @@ def image_of_optic_object(optic_obj, rays):
                                          images.data_ptr(), t.cuda.current_stream().cuda_stream), 'xrt_make_image')
     t.cuda.current_stream().synchronize()
     return images.cpu().numpy()[:o.pixel_nx * o.pixel_ny].reshape(o.pixel_nx, o.pixel_ny).astype(np.float64)
+
+
+# ---------------------------------------------------------------------------
+# TraceObject.intersect / check_bounds / interact as separate device calls
+# ---------------------------------------------------------------------------
+
+def _one_optic(optic_obj, n):
+    """The C struct of one optic (through a one-optic scene, so that all derived constants are the scene's)."""
+    t = _torch()
+    dev = t.device('cuda', t.cuda.current_device())
+    dummy = xscene.ExternalRays(t.zeros((xscene.XRT_HIST_COMPONENTS, max(n, 1)), dtype=t.float64, device=dev),
+                                t.zeros(max(n, 1), dtype=t.uint8, device=dev))
+    flat = xscene.FlatScene(dummy, [optic_obj], ['rays', 'optic'])
+    return flat, flat.struct.optics[0]
+
+
+def _vec_to_device(t, a):
+    """(n, 3) host array -> [3][n] device tensor."""
+    return t.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float64).T)).to(t.device('cuda', t.cuda.current_device()))
+
+
+def optic_intersect(optic_obj, rays):
+    from . import capi
+    t = _torch()
+    n = len(rays['mask'])
+    flat, o = _one_optic(optic_obj, n)
+    d_rays, d_mask = _rays_to_device(rays)
+    xloc = t.empty((3, max(n, 1)), dtype=t.float64, device=d_rays.device)
+    norm = t.empty((3, max(n, 1)), dtype=t.float64, device=d_rays.device)
+    m_out = t.empty(max(n, 1), dtype=t.uint8, device=d_rays.device)
+    capi.check(capi.lib().xrt_optic_intersect(C.byref(o), n, d_rays.data_ptr(), d_mask.data_ptr(), xloc.data_ptr(),
+                                              norm.data_ptr(), m_out.data_ptr(), t.cuda.current_stream().cuda_stream),
+               'xrt_optic_intersect')
+    t.cuda.current_stream().synchronize()
+    rays['mask'][:] = m_out.cpu().numpy()[:n].astype(bool)
+    return (np.ascontiguousarray(xloc.cpu().numpy()[:, :n].T), np.ascontiguousarray(norm.cpu().numpy()[:, :n].T),
+            rays['mask'])
+
+
+def optic_check_bounds(optic_obj, X, mask):
+    from . import capi
+    t = _torch()
+    n = len(mask)
+    flat, o = _one_optic(optic_obj, n)
+    d_x = _vec_to_device(t, X)
+    d_m = t.from_numpy(np.ascontiguousarray(np.asarray(mask), dtype=np.uint8)).to(d_x.device)
+    capi.check(capi.lib().xrt_optic_check_bounds(C.byref(o), n, d_x.data_ptr(), d_m.data_ptr(),
+                                                 t.cuda.current_stream().cuda_stream), 'xrt_optic_check_bounds')
+    t.cuda.current_stream().synchronize()
+    mask[:] = d_m.cpu().numpy().astype(bool)
+    return mask
+
+
+def optic_interact(optic_obj, rays, xloc, norm, mask=None):
+    from . import capi
+    t = _torch()
+    if mask is None:
+        mask = rays['mask']
+    n = len(mask)
+    flat, o = _one_optic(optic_obj, n)
+    d_rays, _ = _rays_to_device(rays)
+    d_x, d_n = _vec_to_device(t, xloc), _vec_to_device(t, norm)
+    d_m = t.from_numpy(np.ascontiguousarray(np.asarray(mask), dtype=np.uint8)).to(d_rays.device)
+    d_test = None
+    if o.interact == xscene.INTERACT['crystal'] and (o.flags & xscene.F_CHECK_BRAGG):
+        # rocking_curve_filter (optics/_InteractCrystal.py:189): one uniform deviate per ray still alive, in ray order
+        live = np.flatnonzero(np.asarray(mask))
+        test = np.zeros(n, dtype=np.float64)
+        test[live] = np.random.uniform(0.0, 1.0, len(live))
+        d_test = t.from_numpy(test).to(d_rays.device)
+    capi.check(capi.lib().xrt_optic_interact(C.byref(o), n, d_rays.data_ptr(), d_x.data_ptr(), d_n.data_ptr(), d_m.data_ptr(),
+                                             d_test.data_ptr() if d_test is not None else None,
+                                             t.cuda.current_stream().cuda_stream), 'xrt_optic_interact')
+    t.cuda.current_stream().synchronize()
+    out = d_rays.cpu().numpy()
+    rays['origin'][:] = out[0:3, :n].T
+    rays['direction'][:] = out[3:6, :n].T
+    new_mask = d_m.cpu().numpy().astype(bool)
+    if isinstance(rays['mask'], np.ndarray) and rays['mask'].shape == new_mask.shape:
+        rays['mask'][:] = new_mask
+    else:
+        rays['mask'] = new_mask
+    return rays
