@@ -671,6 +671,36 @@ __device__ __forceinline__ double bragg_offset(const KOptic& op, const Ray& ray,
     return fabs(bragg - inc);
 }
 
+// ---- rocking-curve screen ----------------------------------------------------------------------------------
+// The decision is p >= test with p = R exp(-(inc - bragg)^2 / 2 sigma^2) (or the step function) and test a
+// uniform deviate.  When every ray has the same wavelength, inc - bragg = asin(c) - asin(s) is a short series
+// in d = c - s (constants from the host, relative error <= 1e-6 inside |d| < scr_dmax), and a single-precision
+// exponential gives p to ~2e-5.  Unless `test` falls within 1e-3 (relative) of that estimate the outcome of
+// the exact evaluation is already known; the exact evaluation then only runs for about one candidate in a
+// thousand (and for test == 0, NaNs, scenes without the screen).  `c`: the cosine of the angle between the ray
+// and the surface normal, exact or good to a few ulp (the margins cover 1e-9).  Sets `decided`.
+__device__ __forceinline__ bool bragg_screen(const KOptic& op, double c, double test, bool& decided)
+{
+    decided = true;
+    const double d = c - op.scr_s;
+    if (fabs(d) < op.scr_dmax) {
+        const double dfa = d * fma(d, fma(d, op.scr_a3, op.scr_a2), op.scr_a1);
+        if (op.rocking_type == XRT_ROCKING_STEP) {
+            const double a = fabs(dfa), m = fma(op.half_fwhm, 1e-6, 1e-12);
+            if (a < op.half_fwhm - m) return op.reflectivity >= test;       // p = 1.0 * R exactly
+            if (a > op.half_fwhm + m) return false;                         // p = 0.0 * R < test
+        } else {
+            const double xa = (dfa * dfa) * op.scr_binv;
+            const float xf = fminf((float)xa, 80.0f);
+            const double pa = (double)__builtin_amdgcn_exp2f(xf * -1.44269504f) * op.reflectivity;
+            if (test > pa * 1.001) return false;
+            if (xa < 80.0 && test < pa * 0.999) return true;
+        }
+    } else if (test > op.scr_ptail) return false;
+    decided = false;
+    return false;
+}
+
 __device__ __forceinline__ bool bragg_accept(const KOptic& op, const Ray& ray, const V3& nrm, double test,
                                              bool have_bragg, double bragg_shared)
 {
@@ -678,29 +708,10 @@ __device__ __forceinline__ bool bragg_accept(const KOptic& op, const Ray& ray, c
     // the reference (:104) is not formed
     double dt = fabs(dot_e(ray.d, nrm));
     const double c = dt / norm3(ray.d);
-    // ---- screen -------------------------------------------------------------------------------------
-    // The decision is p >= test with p = R exp(-(inc - bragg)^2 / 2 sigma^2) (or the step function) and
-    // test a uniform deviate.  When every ray has the same wavelength, inc - bragg = asin(c) - asin(s) is a
-    // short series in d = c - s (constants from the host, relative error <= 1e-6 inside |d| < scr_dmax), and a
-    // single-precision exponential gives p to ~2e-5.  Unless `test` falls within 1e-3 (relative) of that
-    // estimate the outcome of the exact evaluation is already known; the exact evaluation below then only
-    // runs for about one candidate in a thousand (and for test == 0, NaNs, scenes without the screen).
     if (op.scr_ok && have_bragg && test > 0.0) {
-        const double d = c - op.scr_s;
-        if (fabs(d) < op.scr_dmax) {
-            const double dfa = d * fma(d, fma(d, op.scr_a3, op.scr_a2), op.scr_a1);
-            if (op.rocking_type == XRT_ROCKING_STEP) {
-                const double a = fabs(dfa), m = fma(op.half_fwhm, 1e-6, 1e-12);
-                if (a < op.half_fwhm - m) return op.reflectivity >= test;       // p = 1.0 * R exactly
-                if (a > op.half_fwhm + m) return false;                         // p = 0.0 * R < test
-            } else {
-                const double xa = (dfa * dfa) * op.scr_binv;
-                const float xf = fminf((float)xa, 80.0f);
-                const double pa = (double)__builtin_amdgcn_exp2f(xf * -1.44269504f) * op.reflectivity;
-                if (test > pa * 1.001) return false;
-                if (xa < 80.0 && test < pa * 0.999) return true;
-            }
-        } else if (test > op.scr_ptail) return false;
+        bool decided;
+        const bool acc = bragg_screen(op, c, test, decided);
+        if (decided) return acc;
     }
     // ---- exact evaluation, in the reference's order -----------------------------------------------------
     // a monochromatic source gives every ray the same asin argument: evaluated once per run
@@ -715,6 +726,15 @@ __device__ __forceinline__ bool bragg_accept(const KOptic& op, const Ray& ray, c
     }
     p *= op.reflectivity;
     return p >= test;
+}
+
+// The direction of the surface normal at X without its normalisation, for the shapes where that is cheap
+// (what the screen needs is only the cosine of the incidence angle to a few ulp)
+__device__ __forceinline__ bool normal_direction(const KOptic& op, const V3& X, V3& nu)
+{
+    if (op.shape == XRT_SHAPE_PLANE) { nu = ld3(op.R + 6); return true; }
+    if (op.shape == XRT_SHAPE_SPHERE) { nu = sub3(ld3(op.center), X); return true; }
+    return false;
 }
 
 // TraceObject.make_image (optics/_TraceObject.py:234-293): one hit -> one pixel
@@ -1335,6 +1355,15 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
                 rb.o = Xb; rb.d = Xb; rb.wl = 0.0;
                 if (have_b) {
                     q_load(q_wrap(qhead + qcap - bcount + vt), rb.o, rb.d, rb.wl, idb);
+                    if constexpr (!EXT) {
+                        // InteractCrystal.interact -> reflect_vectors (optics/_InteractMirror.py:29-42), deferred from the Bragg stage
+                        const V3 nrm = surface_normal<FULL>(opb, rb.o);
+                        const double dt = dot_e(rb.d, nrm);
+                        rb.d.x = rb.d.x - 2.0 * (dt * nrm.x);
+                        rb.d.y = rb.d.y - 2.0 * (dt * nrm.y);
+                        rb.d.z = rb.d.z - 2.0 * (dt * nrm.z);
+                        if (HIST) hist_write(args.hist, args.hmask, N, be + 1, idb, rb.o, rb.d, rb.wl, true);
+                    }
                     if ((opb.flags & XRT_F_IMAGE) && args.images) image_hit(opb, rb.o, args.images);
                 }
                 bcount -= n;
@@ -1493,24 +1522,27 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
                         }
                     }
                 } else {
+                    // The reflection itself (exact normal: a square root and three divisions) waits until the
+                    // survivors are drained, on dense lanes; here the screen decides nearly every candidate from
+                    // the incidence cosine alone, |d . nu| / (|nu| |d|) with the un-normalised normal direction nu.
                     if (have) {
                         q_load(q_wrap(qhead + vt), X, ray.d, ray.wl, id);
-                        V3 nrm = surface_normal<FULL>(op, X);
                         uint32_t n = spos + 2u * vt;
                         double test = 0.0 + (1.0 - 0.0) * mt_double(stream[n & XRT_RMASK], stream[(n + 1u) & XRT_RMASK]);
-                        alive = bragg_accept(op, ray, nrm, test, wl_shared, bragg_shared);
+                        bool decided = false;
+                        V3 nu;
+                        if (op.scr_ok && wl_shared && test > 0.0 && normal_direction(op, X, nu)) {
+                            const double pp = dot_n(nu, nu) * dot_n(ray.d, ray.d);
+                            double y = __builtin_amdgcn_rsq(pp);
+                            y = y * fma(-0.5 * pp * y, y, 1.5);
+                            alive = bragg_screen(op, fabs(dot_n(ray.d, nu)) * y, test, decided);
+                        }
+                        if (!decided) alive = bragg_accept(op, ray, surface_normal<FULL>(op, X), test, wl_shared, bragg_shared);
 #if XRT_ABLATE == 1
                         alive = alive && (id == 0xffffffffu);
 #endif
                         if (HIST && !alive) hist_write(args.hist, args.hmask, N, be + 1, id, X, ray.d, ray.wl, false);
-                        if (alive) {
-                            ray.o = X;
-                            double dt = dot_e(ray.d, nrm);
-                            ray.d.x = ray.d.x - 2.0 * (dt * nrm.x);
-                            ray.d.y = ray.d.y - 2.0 * (dt * nrm.y);
-                            ray.d.z = ray.d.z - 2.0 * (dt * nrm.z);
-                            if (HIST) hist_write(args.hist, args.hmask, N, be + 1, id, ray.o, ray.d, ray.wl, true);
-                        }
+                        if (alive) ray.o = X;
                     }
                 }
                 spos += 2u * nb;
