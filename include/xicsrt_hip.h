@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define XRT_ABI_VERSION 14
+#define XRT_ABI_VERSION 15
 
 #define XRT_MAX_OPTICS     16
 #define XRT_MAX_APERTURES  8
@@ -377,6 +377,11 @@ int xrt_optic_intersect(const xrt_optic_t* optic, int64_t n, const double* rays,
 int xrt_optic_check_bounds(const xrt_optic_t* optic, int64_t n, const double* xloc, uint8_t* mask, void* stream);
 int xrt_optic_interact(const xrt_optic_t* optic, int64_t n, double* rays, const double* xloc, const double* norm,
                        uint8_t* mask, const double* test, void* stream);
+
+/* Self-test: the shared-reciprocal division the kernels use to normalise 3-vectors (three IEEE quotients with one
+ * reciprocal) against the division operator, on caller-supplied operands (device: num [3][n], den [n]); *bad (device,
+ * caller-zeroed) counts the quotients whose bits differ.  No reference counterpart. */
+int xrt_selftest_div3(const double* num, const double* den, int64_t n, uint64_t* bad, void* stream);
 
 /* Diagnostics: the device routes taken by this thread's xrt_trace / xrt_trace_history calls since the last
  * call with reset != 0 (bit set below).  The routes are picked per scene; the environment switches

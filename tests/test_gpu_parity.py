@@ -296,3 +296,30 @@ def test_plasma_errors_surface_as_the_references_value_errors():
     cfg['general'].update(keep_history=False)
     with pytest.raises(ValueError, match='intensity of less than one encountered'):
         xicsrt_amd.raytrace(cfg)
+
+
+@pytest.mark.gpu
+def test_shared_reciprocal_division_is_the_ieee_quotient(devlib):
+    """div3_rn (one reciprocal for three numerators) against the / operator: 3 x 4e6 quotients over operands of
+    every scale the kernels can meet and far beyond (zeros, signed zeros, huge and tiny lengths, NaN, inf)."""
+    import torch
+    rs = np.random.RandomState(5)
+    n = 4000000
+    den = rs.uniform(0.5, 2.0, n) * 2.0 ** rs.randint(-40, 40, n)
+    num = rs.uniform(-1.0, 1.0, (3, n)) * den * 2.0 ** rs.randint(-60, 2, (3, n))
+    den[:1000] *= 2.0 ** rs.choice([-600, -520, 520, 600, 900, -900], 1000)       # the plain-division branch
+    num[:, 1000:1200] = 0.0
+    num[0, 1200:1300] = -0.0
+    num[1, 1300:1400] = np.inf
+    num[2, 1400:1500] = np.nan
+    den[1500:1520] = 0.0
+    den[1520:1540] = np.inf
+    num[:, 2000:3000] = rs.uniform(-1, 1, (3, 1000)) * 2.0 ** rs.randint(-1000, -300, (3, 1000))     # tiny components
+    d_num = torch.from_numpy(num).cuda()
+    d_den = torch.from_numpy(den).cuda()
+    bad = torch.zeros(1, dtype=torch.int64, device='cuda')
+    from xicsrt_amd import capi
+    capi.check(devlib.xrt_selftest_div3(d_num.data_ptr(), d_den.data_ptr(), n, bad.data_ptr(),
+                                        torch.cuda.current_stream().cuda_stream), 'xrt_selftest_div3')
+    torch.cuda.synchronize()
+    assert int(bad.item()) == 0

@@ -138,6 +138,9 @@ struct KOptic {
     int32_t scr_ok;                     // rocking-curve screen usable (one wavelength for all rays), see bragg_accept
     double  scr_s, scr_a1, scr_a2, scr_a3;      // sin(bragg) and the series of asin(s + d) - asin(s) in d
     double  scr_binv, scr_dmax, scr_ptail;      // 1 / (2 sigma^2), validity radius in d, bound on p outside it
+    // screen for rays with their own wavelength: inc - bragg from sin(inc - bragg) = c sqrt(1-s^2) - s sqrt(1-c^2)
+    double  scr2_tail, inv_two_d;               // bound on p for |sin(inc - bragg)| >= 0.01; 1 / (2 d)
+    int32_t scr2_ok, pad3;
 };
 
 struct KScene {
@@ -243,6 +246,31 @@ __device__ __forceinline__ double sqrt_rn(double x)
     return fma(d, h, g);
 }
 __device__ __forceinline__ double norm3(const V3& a) { return sqrt_rn(dot_n(a, a)); }
+
+// v / m for the three components of v, each the correctly rounded IEEE quotient: the hardware division
+// sequence (v_rcp_f64, two Newton steps on the reciprocal, quotient, one residual correction, v_div_fixup for
+// zeros / infinities / NaNs) with the reciprocal shared by the three numerators.  The library's per-division
+// v_div_scale only rescales operands near the ends of the exponent range: m outside [2^-511, 2^512) takes the
+// plain divisions; the numerators here are components of the vector whose length m is (|v_i| <= m, and sums and
+// differences of O(1) coordinates are never within 2^-500 of zero without being zero).
+// xrt_selftest_div3 holds this to the / operator on the GPU, tiny and huge operands included.
+__device__ __forceinline__ V3 div3_rn(const V3& v, double m)
+{
+    V3 q;
+    if (!(((uint32_t)__double2hiint(m) & 0x7fffffffu) - 0x20000000u < 0x40000000u)) {
+        q.x = v.x / m; q.y = v.y / m; q.z = v.z / m;
+        return q;
+    }
+    double r = __builtin_amdgcn_rcp(m);
+    double e = fma(-m, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-m, r, 1.0);
+    r = fma(r, e, r);
+    double t = v.x * r; t = fma(fma(-m, t, v.x), r, t); q.x = __builtin_amdgcn_div_fixup(t, m, v.x);
+    t = v.y * r; t = fma(fma(-m, t, v.y), r, t); q.y = __builtin_amdgcn_div_fixup(t, m, v.y);
+    t = v.z * r; t = fma(fma(-m, t, v.z), r, t); q.z = __builtin_amdgcn_div_fixup(t, m, v.z);
+    return q;
+}
 __device__ __forceinline__ V3 cross3(const V3& a, const V3& b)
 {
     V3 c;
@@ -367,15 +395,12 @@ __device__ __forceinline__ void source_ray(const KSource& s, const double* u, Ra
     V3 n, o1, o2;
     if (FULL && s.kind == XRT_SRC_FOCUSED) {
         V3 a = sub3(ld3(s.axis), ray.o);
-        double m = norm3(a);
-        n.x = a.x / m; n.y = a.y / m; n.z = a.z / m;
+        n = div3_rn(a, norm3(a));
         V3 c1 = cross3(n, ld3(s.xaxis)), c2 = cross3(n, ld3(s.zaxis));
         o1.x = c1.x + c2.x; o1.y = c1.y + c2.y; o1.z = c1.z + c2.z;
-        double m1 = norm3(o1);
-        o1.x /= m1; o1.y /= m1; o1.z /= m1;
+        o1 = div3_rn(o1, norm3(o1));
         o2 = cross3(n, o1);
-        double m2 = norm3(o2);
-        o2.x /= m2; o2.y /= m2; o2.z /= m2;
+        o2 = div3_rn(o2, norm3(o2));
     } else {
         o2 = ld3(s.basis + 0); o1 = ld3(s.basis + 3); n = ld3(s.basis + 6);
     }
@@ -574,8 +599,7 @@ __device__ __forceinline__ V3 surface_normal(const KOptic& op, const V3& X)
         nrm = ld3(op.R + 6);                        // optics/_ShapePlane.py:56-62
     } else if (!FULL || op.shape == XRT_SHAPE_SPHERE) {
         V3 q = sub3(ld3(op.center), X);             // optics/_ShapeSphere.py:102-106
-        double m = norm3(q);
-        nrm.x = q.x / m; nrm.y = q.y / m; nrm.z = q.z / m;
+        nrm = div3_rn(q, norm3(q));
     } else if (op.shape == XRT_SHAPE_TORUS) {
         // optics/_ShapeTorus.py:186-216: away from the nearest point of the major circle
         V3 C = ld3(op.center), ya = ld3(op.R + 3);
@@ -679,25 +703,47 @@ __device__ __forceinline__ double bragg_offset(const KOptic& op, const Ray& ray,
 // the exact evaluation is already known; the exact evaluation then only runs for about one candidate in a
 // thousand (and for test == 0, NaNs, scenes without the screen).  `c`: the cosine of the angle between the ray
 // and the surface normal, exact or good to a few ulp (the margins cover 1e-9).  Sets `decided`.
-__device__ __forceinline__ bool bragg_screen(const KOptic& op, double c, double test, bool& decided)
+__device__ __forceinline__ bool screen_df(const KOptic& op, double dfa, double test, bool& decided)
 {
     decided = true;
-    const double d = c - op.scr_s;
-    if (fabs(d) < op.scr_dmax) {
-        const double dfa = d * fma(d, fma(d, op.scr_a3, op.scr_a2), op.scr_a1);
-        if (op.rocking_type == XRT_ROCKING_STEP) {
-            const double a = fabs(dfa), m = fma(op.half_fwhm, 1e-6, 1e-12);
-            if (a < op.half_fwhm - m) return op.reflectivity >= test;       // p = 1.0 * R exactly
-            if (a > op.half_fwhm + m) return false;                         // p = 0.0 * R < test
-        } else {
-            const double xa = (dfa * dfa) * op.scr_binv;
-            const float xf = fminf((float)xa, 80.0f);
-            const double pa = (double)__builtin_amdgcn_exp2f(xf * -1.44269504f) * op.reflectivity;
-            if (test > pa * 1.001) return false;
-            if (xa < 80.0 && test < pa * 0.999) return true;
-        }
-    } else if (test > op.scr_ptail) return false;
+    if (op.rocking_type == XRT_ROCKING_STEP) {
+        const double a = fabs(dfa), m = fma(op.half_fwhm, 1e-6, 1e-12);
+        if (a < op.half_fwhm - m) return op.reflectivity >= test;       // p = 1.0 * R exactly
+        if (a > op.half_fwhm + m) return false;                         // p = 0.0 * R < test
+    } else {
+        const double xa = (dfa * dfa) * op.scr_binv;
+        const float xf = fminf((float)xa, 80.0f);
+        const double pa = (double)__builtin_amdgcn_exp2f(xf * -1.44269504f) * op.reflectivity;
+        if (test > pa * 1.001) return false;
+        if (xa < 80.0 && test < pa * 0.999) return true;
+    }
     decided = false;
+    return false;
+}
+
+__device__ __forceinline__ bool bragg_screen(const KOptic& op, double c, double test, bool& decided)
+{
+    const double d = c - op.scr_s;
+    if (fabs(d) < op.scr_dmax) return screen_df(op, d * fma(d, fma(d, op.scr_a3, op.scr_a2), op.scr_a1), test, decided);
+    decided = test > op.scr_ptail;
+    return false;
+}
+
+// The same for a ray with its own wavelength (s = wl / 2d): sin(inc - bragg) = c sqrt(1 - s^2) - s sqrt(1 - c^2)
+// from approximate square roots (absolute error ~1e-15), inc - bragg = asin(y) = y + y^3/6 to 1e-9 relative for
+// |y| < 0.01; beyond that |inc - bragg| >= |y| bounds p (scr2_tail).
+__device__ __forceinline__ double sqrt_approx(double u)
+{
+    double y = __builtin_amdgcn_rsq(u);
+    y = y * fma(-0.5 * u * y, y, 1.5);
+    return u * y;
+}
+__device__ __forceinline__ bool bragg_screen_wl(const KOptic& op, double c, double wl, double test, bool& decided)
+{
+    const double s = wl * op.inv_two_d;
+    const double y = c * sqrt_approx(fma(-s, s, 1.0)) - s * sqrt_approx(fma(-c, c, 1.0));
+    if (fabs(y) < 0.01) return screen_df(op, y * fma(y * y, 0.16666666666666666, 1.0), test, decided);
+    decided = (fabs(y) >= 0.01) && (test > op.scr2_tail);       // (a NaN y decides nothing)
     return false;
 }
 
@@ -1531,11 +1577,13 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
                         double test = 0.0 + (1.0 - 0.0) * mt_double(stream[n & XRT_RMASK], stream[(n + 1u) & XRT_RMASK]);
                         bool decided = false;
                         V3 nu;
-                        if (op.scr_ok && wl_shared && test > 0.0 && normal_direction(op, X, nu)) {
+                        if (test > 0.0 && ((op.scr_ok && wl_shared) || op.scr2_ok) && normal_direction(op, X, nu)) {
                             const double pp = dot_n(nu, nu) * dot_n(ray.d, ray.d);
                             double y = __builtin_amdgcn_rsq(pp);
                             y = y * fma(-0.5 * pp * y, y, 1.5);
-                            alive = bragg_screen(op, fabs(dot_n(ray.d, nu)) * y, test, decided);
+                            const double ca = fabs(dot_n(ray.d, nu)) * y;
+                            alive = (op.scr_ok && wl_shared) ? bragg_screen(op, ca, test, decided)
+                                                             : bragg_screen_wl(op, ca, ray.wl, test, decided);
                         }
                         if (!decided) alive = bragg_accept(op, ray, surface_normal<FULL>(op, X), test, wl_shared, bragg_shared);
 #if XRT_ABLATE == 1
@@ -1986,10 +2034,21 @@ static void bragg_screen(const xrt_source_t& src, KOptic& q)
     q.scr_ok = 0;
     q.scr_s = q.scr_a1 = q.scr_a2 = q.scr_a3 = q.scr_binv = q.scr_dmax = 0.0;
     q.scr_ptail = INFINITY;
+    q.scr2_ok = 0; q.scr2_tail = INFINITY; q.inv_two_d = 0.0;
     if (q.interact != XRT_INTERACT_CRYSTAL || !(q.flags & XRT_F_CHECK_BRAGG)) return;
-    if (src.wavelength_dist != XRT_WL_CONST || src.has_velocity) return;
     const double R = q.reflectivity;
     if (!(R >= 0.0) || !std::isfinite(R)) return;
+    // rays with their own wavelength: |sin(inc - bragg)| >= 0.01 must put p below every non-zero deviate
+    if (q.two_d > 0.0 && std::isfinite(q.two_d)) {
+        q.inv_two_d = 1.0 / q.two_d;
+        if (q.rocking_type == XRT_ROCKING_STEP) {
+            if (q.half_fwhm >= 0.0 && q.half_fwhm < 0.0099) { q.scr2_ok = 1; q.scr2_tail = 0.0; }
+        } else if (q.two_sigma2 > 0.0 && std::isfinite(q.two_sigma2) && 1e-4 / q.two_sigma2 >= 46.0) {
+            q.scr_binv = 1.0 / q.two_sigma2;
+            q.scr2_ok = 1; q.scr2_tail = R * exp(-45.0) * 1.001;
+        }
+    }
+    if (src.wavelength_dist != XRT_WL_CONST || src.has_velocity) return;
     const double s0 = (1.0 * src.wavelength) / q.two_d;
     if (!(fabs(s0) < 0.995)) return;
     const double u = 1.0 - s0 * s0;
@@ -2901,6 +2960,30 @@ extern "C" int xrt_optic_interact(const xrt_optic_t* optic, int64_t n, double* r
         return fail(-1, "%s", "a Bragg test needs one uniform deviate per ray");
     hipLaunchKernelGGL(xrt_step_interact_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_),
                        k, n, rays, xloc, norm, mask, test);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// Self-test of div3_rn against the division operator: num [3][n], den [n] (device); counts the quotients whose bits differ.
+__global__ void xrt_selftest_div3_kernel(const double* num, const double* den, int64_t n, unsigned long long* bad)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    V3 v; v.x = num[i]; v.y = num[n + i]; v.z = num[2 * n + i];
+    const double m = den[i];
+    const V3 q = div3_rn(v, m);
+    const double r0 = v.x / m, r1 = v.y / m, r2 = v.z / m;
+    int c = (__double_as_longlong(q.x) != __double_as_longlong(r0) && !(q.x != q.x && r0 != r0))
+          + (__double_as_longlong(q.y) != __double_as_longlong(r1) && !(q.y != q.y && r1 != r1))
+          + (__double_as_longlong(q.z) != __double_as_longlong(r2) && !(q.z != q.z && r2 != r2));
+    if (c) atomicAdd(bad, (unsigned long long)c);
+}
+
+extern "C" int xrt_selftest_div3(const double* num, const double* den, int64_t n, uint64_t* bad, void* stream_)
+{
+    if (!num || !den || !bad || n <= 0) return fail(-1, "%s", "bad argument");
+    hipLaunchKernelGGL(xrt_selftest_div3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_),
+                       num, den, n, reinterpret_cast<unsigned long long*>(bad));
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -20,7 +20,7 @@ import ctypes as C
 
 import numpy as np
 
-XRT_ABI_VERSION = 14
+XRT_ABI_VERSION = 15
 XRT_MAX_BUNDLE_FILTERS = 4
 XRT_MAX_OPTICS = 16
 XRT_MAX_APERTURES = 8
