@@ -411,3 +411,18 @@ def test_cfg5_toroidal_mesh_crystal_41x41_1e9_photons(tag):
     n_gpu, i_gpu = _trace(flat, seeds[:4])
     n_cpu, i_cpu = helpers.oracle_counts(flat, seeds[:4], 1, threads=4)
     assert np.array_equal(n_gpu, n_cpu) and np.array_equal(i_gpu[:flat.image_bins], i_cpu[:flat.image_bins])
+
+
+def test_plasma_runs_in_several_batches(monkeypatch):
+    """More runs than run slots for the scout's stream dumps: batches of slots, same integers."""
+    cfg, gold = helpers.load_golden('F_cfg4_plasma_counts')
+    cfg = copy.deepcopy(cfg)
+    cfg['general'].update(number_of_runs=37)
+    config, elements, flat = helpers.build(cfg)
+    seeds = xrt.run_seeds(config['general']['random_seed'], 37)
+    n_one, i_one = _trace(flat, seeds)
+    monkeypatch.setenv('XICSRT_PLASMA_SLOTS', '8')
+    n_many, i_many = _trace(flat, seeds)
+    assert np.array_equal(n_one, n_many) and np.array_equal(i_one, i_many)
+    n_cpu, i_cpu = helpers.oracle_counts(flat, seeds, 1, threads=8)
+    assert np.array_equal(n_many, n_cpu) and np.array_equal(i_many[:flat.image_bins], i_cpu[:flat.image_bins])

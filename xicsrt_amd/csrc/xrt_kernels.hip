@@ -1816,9 +1816,11 @@ static bool optics_need_staged(const xrt_scene_t* sc)
 }
 // A plasma scene whose optics the fused kernel can take: scout kernel + fused kernel (xrt_plasma.inc); only
 // xrt_trace_history (one run, history) still sends such a scene through the staged kernel.
+static size_t plasma_dump_words(const xrt_scene_t* sc);
 static bool plasma_fused(const xrt_scene_t* sc)
 {
-    return sc->source.kind == XRT_SRC_PLASMA && !optics_need_staged(sc) && !getenv("XICSRT_PLASMA_STAGED");
+    return sc->source.kind == XRT_SRC_PLASMA && !optics_need_staged(sc) && !getenv("XICSRT_PLASMA_STAGED") &&
+           plasma_dump_words(sc) < (1ull << 31);       // the scout indexes its stream with 32 bits
 }
 
 static bool needs_staged(const xrt_scene_t* sc)
@@ -1907,6 +1909,7 @@ static size_t plasma_slot_bytes(const xrt_scene_t* sc)
 static int plasma_slots(const xrt_scene_t* sc, int n_runs)
 {
     size_t s = XRT_ST_BUDGET / plasma_slot_bytes(sc);
+    if (const char* e = getenv("XICSRT_PLASMA_SLOTS")) { const int v = atoi(e); if (v >= 1 && (size_t)v < s) s = (size_t)v; }   // tests: several batches
     if (s < 1) s = 1;
     if ((size_t)n_runs < s) s = (size_t)(n_runs < 1 ? 1 : n_runs);
     return (int)s;
@@ -2433,7 +2436,7 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
         ps.ray_bundle = reinterpret_cast<uint32_t*>(p);                 p += (size_t)slots * al256(NN * 4);
         ps.wl = reinterpret_cast<double*>(p);                           p += (size_t)slots * al256(NN * 8);
         ps.dump = reinterpret_cast<uint32_t*>(p);
-        ps.dump_words = plasma_dump_words(sc);
+        ps.dump_words = (uint32_t)plasma_dump_words(sc);
         // (slot strides: the arrays are indexed [slot][...] with the unpadded sizes; al256 only pads the regions)
         ps.gauss_state = reinterpret_cast<KState*>(ws + ws_off_gauss(sc, n_runs));
         ps.flags = reinterpret_cast<uint32_t*>(ws) + 16;
