@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_PHOTON = 142.0       # 68 + 70.9 + 2.9 + 0.7
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+PEAK_CLOCK_GHZ = 2.4                 # MI355X_MICROARCH.md: peak engine clock; VALU issue peak = 1024 SIMDs x clock / 4
 
 
 def spectrometer_config(n_rays, n_runs, seed=0):
@@ -203,13 +204,14 @@ def main():
                 # the real limiter: vector-instruction issue (binary64 geometry + MT19937), from the committed
                 # SQ pass of the same command; `achieved` = wave-instructions issued per second on this run
                 vpp = sqd['valu_wave_instr_per_64_photons'] / 64.0
-                clock = sqd.get('clock_GHz_under_load', 2.4)
+                clock = PEAK_CLOCK_GHZ                     # devices of the pool sustain 2.2-2.3 GHz under this load
                 issued = vpp * per_launch_photons / kavg_s if kavg_s > 0 else 0.0
                 peak = 1024.0 * clock * 1e9 / 4.0          # 1024 SIMDs, one wave64 VALU instruction per 4 cycles
                 line['roofline_valu'] = {
                     'bound': 'valu_issue', 'achieved': issued / 1e9, 'peak': peak / 1e9, 'unit': 'G wave-instr/s',
                     'frac': issued / peak if peak > 0 else None,
-                    'valu_wave_instr_per_photon': vpp, 'clock_GHz_under_load': clock,
+                    'valu_wave_instr_per_photon': vpp, 'peak_clock_GHz': clock,
+                    'clock_GHz_under_load_in_profile_pass': sqd.get('clock_GHz_under_load'),
                     'busy_fraction_in_profile_pass': sqd.get('valu_issue_busy_fraction'),
                     'source': prof_file}
                 line['roofline']['limiter'] = 'valu_issue (see roofline_valu); HBM carries only the histogram atomics'
