@@ -98,21 +98,31 @@ struct KSource {
     const uint8_t* ext_mask;
 };
 
+// Mesh tables live in global memory and are only ever read: typed pointers (address space 1 / 4) keep the
+// compiler from emitting generic (flat) loads; what a wave walks in lockstep goes through scalar loads.
+#define XRT_C4 __attribute__((address_space(4)))
+#define XRT_G1 __attribute__((address_space(1)))
+typedef const XRT_G1 double*  gdp;
+typedef const XRT_G1 int32_t* gip;
+typedef double  d4v __attribute__((ext_vector_type(4)));
+typedef int32_t i4v __attribute__((ext_vector_type(4)));
+struct KCellRec { double x, y, z; int32_t idx, next; };      // a point of an x-y bucket; next: chain inside the bucket, -1 ends it
+struct KFaceRec { double p0[3], p1[3], p2[3], n[3], area, pad[3]; };   // what mesh_intersect_2 reads of a face, 128 B
+
 struct KMesh {               // device pointers, see xrt_mesh_t
-    int32_t n_points, n_faces, n_coarse_faces, interpolate, n_simplices, pad;
-    const double *points, *p0, *p1, *p2, *edge1, *edge2, *faces_normal, *faces_area;
-    const int32_t* p_faces_idx;
-    const uint8_t* p_faces_mask;
-    const double *c_p0, *c_edge1, *c_edge2;
-    const int32_t *ct_simplices, *ct_neighbors;
-    const double *ct_transform, *ct_points, *ct_values, *ct_grad;
-    const int32_t* ct_vertex_simplex;
+    int32_t n_points, n_faces, n_coarse_faces, interpolate, n_simplices, n_first;
+    gdp faces_normal;
+    const double* first_rec;        // [n_first + 1][10] p0, edge1, edge2 of the faces mesh_intersect_1 walks (coarse faces, or all)
+    const XRT_G1 d4v* face_rec;     // [n_faces] KFaceRec, read as four 32-byte vectors
+    gip point_faces;                // [n_points][8] the faces around a point, -1 where the reference's mask is False
+    gip ct_simplices, ct_neighbors;
+    gdp ct_transform, ct_points, ct_values, ct_grad;
+    gip ct_vertex_simplex;
     // x-y bucket grid over the points for the exact nearest-point search (built by the library)
     int32_t grid_nx, grid_ny;
     double  grid_x0, grid_y0, grid_hx, grid_hy, grid_ihx, grid_ihy, grid_tiny;
-    const int32_t* cell_start;      // [nx*ny + 1]
-    const int32_t* cell_idx;        // [n_points] point indices bucket by bucket, ascending inside a bucket
-    const double*  cell_xyz;        // [n_points][3] the points in that order
+    gdp points;                     // [n_points][3] (search without a grid)
+    const XRT_G1 d4v* cells;        // KCellRec [nx*ny] first point of every bucket (idx -1: empty), then the chained ones
 };
 
 struct KOptic {
@@ -1018,7 +1028,6 @@ struct KArgs {
 // ~150 scalar registers into vector-register lanes (v_writelane / v_readlane are VALU work in the
 // hot loop).  scene_fresh() hands the same pointer back through an empty asm: loads behind it
 // cannot move above it, which keeps the live ranges of the scene constants inside one stage.
-#define XRT_C4 __attribute__((address_space(4)))
 __device__ __forceinline__ const KScene* scene_fresh(const KScene* p)
 {
     uint64_t a = (uint64_t)p;
@@ -1856,9 +1865,10 @@ static size_t mesh_bytes(const xrt_mesh_t* m)
     if (!m) return 0;
     size_t b = al256(sizeof(KMesh));
     const size_t P = (size_t)m->n_points, F = (size_t)m->n_faces, Cn = (size_t)m->n_coarse_faces, T = (size_t)m->n_simplices;
-    b += al256(P * 3 * 8) + 7 * al256(F * 3 * 8) + al256(P * 8 * 4) + al256(P * 8) + 3 * al256(Cn * 3 * 8 + 8);
+    const size_t n_first = Cn > 0 ? Cn : F;
+    b += al256(F * 24) + al256((n_first + 1) * 80) + al256(F * sizeof(KFaceRec)) + al256(P * 32) + al256(P * 24);
     if (m->interpolate) b += 2 * al256(T * 3 * 4) + al256(T * 6 * 8) + al256(P * 2 * 8) + al256(4 * P * 8) + al256(8 * P * 8) + al256(P * 4);
-    b += al256((P + 2) * 4) + al256(P * 4) + al256(P * 24);          // bucket grid: <= P buckets
+    b += al256((2 * P + 1) * sizeof(KCellRec));                       // bucket grid: <= P buckets + <= P chained points
     return b;
 }
 static size_t meshes_bytes(const xrt_scene_t* sc)
@@ -2199,36 +2209,55 @@ static int upload_meshes(const xrt_scene_t* sc, char* ws, int n_runs, KScene* ks
         ks->opt[e].mesh = nullptr;
         if (sc->optics[e].shape != XRT_SHAPE_MESH) continue;
         const xrt_mesh_t* m = sc->optics[e].mesh;
-        static thread_local KMesh hk[XRT_DEV_MAX_OPTICS];
-        KMesh& k = hk[e];
+        KMesh k;
         memset(&k, 0, sizeof(k));
         k.n_points = m->n_points; k.n_faces = m->n_faces; k.n_coarse_faces = m->n_coarse_faces;
         k.interpolate = m->interpolate; k.n_simplices = m->n_simplices;
         char* p = base + al256(sizeof(KMesh));
-        auto put = [&](const void* src, size_t bytes) -> const void* {
+        // synchronous copies throughout: the packed tables are host temporaries
+        auto put = [&](const void* src, size_t bytes) -> uintptr_t {
             char* dst = p;
             p += al256(bytes > 0 ? bytes : 8);
-            if (src && bytes) (void)hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream);
-            return dst;
+            if (src && bytes) (void)hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+            return (uintptr_t)dst;
         };
         const size_t P = (size_t)m->n_points, F = (size_t)m->n_faces, Cn = (size_t)m->n_coarse_faces, T = (size_t)m->n_simplices;
-        k.points = (const double*)put(m->points, P * 24);
-        k.p0 = (const double*)put(m->p0, F * 24); k.p1 = (const double*)put(m->p1, F * 24); k.p2 = (const double*)put(m->p2, F * 24);
-        k.edge1 = (const double*)put(m->edge1, F * 24); k.edge2 = (const double*)put(m->edge2, F * 24);
-        k.faces_normal = (const double*)put(m->faces_normal, F * 24);
-        k.faces_area = (const double*)put(m->faces_area, F * 8);
-        k.p_faces_idx = (const int32_t*)put(m->p_faces_idx, P * 32);
-        k.p_faces_mask = (const uint8_t*)put(m->p_faces_mask, P * 8);
-        k.c_p0 = (const double*)put(m->c_p0, Cn * 24); k.c_edge1 = (const double*)put(m->c_edge1, Cn * 24);
-        k.c_edge2 = (const double*)put(m->c_edge2, Cn * 24);
+        k.faces_normal = (gdp)put(m->faces_normal, F * 24);
+        {   // faces of the first (exhaustive) Moller-Trumbore pass, one 80-byte record each (+1: the walk reads one ahead)
+            const size_t n_first = Cn > 0 ? Cn : F;
+            const double *q0 = Cn > 0 ? m->c_p0 : m->p0, *q1 = Cn > 0 ? m->c_edge1 : m->edge1, *q2 = Cn > 0 ? m->c_edge2 : m->edge2;
+            std::vector<double> rec((n_first + 1) * 10, 0.0);
+            for (size_t i = 0; i < n_first; i++)
+                for (int a = 0; a < 3; a++) { rec[10 * i + a] = q0[3 * i + a]; rec[10 * i + 3 + a] = q1[3 * i + a]; rec[10 * i + 6 + a] = q2[3 * i + a]; }
+            k.n_first = (int32_t)n_first;
+            k.first_rec = (const double*)put(rec.data(), rec.size() * 8);
+        }
+        {   // per face what the second pass reads, per point its <= 8 faces
+            std::vector<KFaceRec> fr(F);
+            for (size_t i = 0; i < F; i++) {
+                memset(&fr[i], 0, sizeof(KFaceRec));
+                for (int a = 0; a < 3; a++) {
+                    fr[i].p0[a] = m->p0[3 * i + a]; fr[i].p1[a] = m->p1[3 * i + a]; fr[i].p2[a] = m->p2[3 * i + a];
+                    fr[i].n[a] = m->faces_normal[3 * i + a];
+                }
+                fr[i].area = m->faces_area[i];
+            }
+            k.face_rec = (const XRT_G1 d4v*)put(fr.data(), F * sizeof(KFaceRec));
+            std::vector<int32_t> pf(P * 8);
+            for (size_t i = 0; i < P; i++)
+                for (int j = 0; j < 8; j++)
+                    pf[8 * i + j] = m->p_faces_mask[(size_t)j * P + i] ? m->p_faces_idx[(size_t)j * P + i] : -1;
+            k.point_faces = (gip)put(pf.data(), P * 32);
+        }
+        k.points = (gdp)put(m->points, P * 24);
         if (m->interpolate) {
-            k.ct_simplices = (const int32_t*)put(m->ct_simplices, T * 12);
-            k.ct_neighbors = (const int32_t*)put(m->ct_neighbors, T * 12);
-            k.ct_transform = (const double*)put(m->ct_transform, T * 48);
-            k.ct_points = (const double*)put(m->ct_points, P * 16);
-            k.ct_values = (const double*)put(m->ct_values, 4 * P * 8);
-            k.ct_grad = (const double*)put(m->ct_grad, 8 * P * 8);
-            k.ct_vertex_simplex = (const int32_t*)put(m->ct_vertex_simplex, P * 4);
+            k.ct_simplices = (gip)put(m->ct_simplices, T * 12);
+            k.ct_neighbors = (gip)put(m->ct_neighbors, T * 12);
+            k.ct_transform = (gdp)put(m->ct_transform, T * 48);
+            k.ct_points = (gdp)put(m->ct_points, P * 16);
+            k.ct_values = (gdp)put(m->ct_values, 4 * P * 8);
+            k.ct_grad = (gdp)put(m->ct_grad, 8 * P * 8);
+            k.ct_vertex_simplex = (gip)put(m->ct_vertex_simplex, P * 4);
         }
         if (m->n_coarse_faces > 0 && P > 0) {
             // x-y bucket grid for the nearest-point search, about one point per bucket
@@ -2253,39 +2282,29 @@ static int upload_meshes(const xrt_scene_t* sc, char* ws, int n_runs, KScene* ks
                 k.grid_hx = ext[0] / nx; k.grid_hy = ext[1] / ny;
                 k.grid_ihx = 1.0 / k.grid_hx; k.grid_ihy = 1.0 / k.grid_hy;
                 k.grid_tiny = 1e-9 * (k.grid_hx > k.grid_hy ? k.grid_hx : k.grid_hy);
-                static thread_local std::vector<int32_t> cstart, cidx, ccell;
-                static thread_local std::vector<double> cxyz;
                 const size_t NC = (size_t)nx * ny;
-                cstart.assign(NC + 1, 0); cidx.resize(P); ccell.resize(P); cxyz.resize(3 * P);
-                for (size_t i = 0; i < P; i++) {
+                std::vector<KCellRec> cells(NC);
+                for (size_t c = 0; c < NC; c++) { cells[c].x = cells[c].y = cells[c].z = 0.0; cells[c].idx = -1; cells[c].next = -1; }
+                std::vector<int32_t> tail(NC, -1);                // last record of every bucket's chain
+                for (size_t i = 0; i < P; i++) {                  // ascending point index along a chain
                     double fx = floor((m->points[3 * i] - k.grid_x0) * k.grid_ihx), fy = floor((m->points[3 * i + 1] - k.grid_y0) * k.grid_ihy);
                     if (!(fx >= 0.0)) fx = 0.0;
                     if (!(fy >= 0.0)) fy = 0.0;
                     const int cx = fx > (double)(nx - 1) ? nx - 1 : (int)fx, cy = fy > (double)(ny - 1) ? ny - 1 : (int)fy;
-                    ccell[i] = cy * nx + cx;
-                    cstart[(size_t)ccell[i] + 1]++;
+                    const size_t c = (size_t)cy * nx + cx;
+                    KCellRec r;
+                    r.x = m->points[3 * i]; r.y = m->points[3 * i + 1]; r.z = m->points[3 * i + 2]; r.idx = (int32_t)i; r.next = -1;
+                    if (tail[c] < 0) { cells[c] = r; tail[c] = (int32_t)c; }
+                    else { cells[(size_t)tail[c]].next = (int32_t)cells.size(); tail[c] = (int32_t)cells.size(); cells.push_back(r); }
                 }
-                for (size_t c = 0; c < NC; c++) cstart[c + 1] += cstart[c];
-                std::vector<int32_t> fill(cstart.begin(), cstart.end() - 1);
-                for (size_t i = 0; i < P; i++) {                 // ascending point index inside a bucket
-                    const int32_t o = fill[ccell[i]]++;
-                    cidx[o] = (int32_t)i;
-                    for (int a = 0; a < 3; a++) cxyz[3 * (size_t)o + a] = m->points[3 * i + a];
-                }
-                // synchronous copies: the vectors are reused by the next call
-                char* d0 = p; p += al256((P + 2) * 4);
-                char* d1 = p; p += al256(P * 4);
-                char* d2 = p; p += al256(P * 24);
-                HIP_TRY(hipMemcpy(d0, cstart.data(), (NC + 1) * 4, hipMemcpyHostToDevice));
-                HIP_TRY(hipMemcpy(d1, cidx.data(), P * 4, hipMemcpyHostToDevice));
-                HIP_TRY(hipMemcpy(d2, cxyz.data(), P * 24, hipMemcpyHostToDevice));
-                k.cell_start = (const int32_t*)d0; k.cell_idx = (const int32_t*)d1; k.cell_xyz = (const double*)d2;
+                k.cells = (const XRT_G1 d4v*)put(cells.data(), cells.size() * sizeof(KCellRec));
             }
         }
-        HIP_TRY(hipMemcpyAsync(base, &k, sizeof(KMesh), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpy(base, &k, sizeof(KMesh), hipMemcpyHostToDevice));
         ks->opt[e].mesh = reinterpret_cast<const KMesh*>(base);
         base += mesh_bytes(m);
     }
+    (void)stream;
     return 0;
 }
 
