@@ -137,7 +137,7 @@ def test_library_exports_every_declared_symbol():
     """The C ABI library loads without a GPU and exports every function include/xicsrt_hip.h declares."""
     header = open(os.path.join(helpers.ROOT, 'include', 'xicsrt_hip.h')).read()
     body = header[header.index('/* ---- entry points'):]
-    declared = set(re.findall(r'\b(xrt_[a-z_]+)\s*\(', body))
+    declared = set(re.findall(r'\b(xrt_[a-z_0-9]+)\s*\(', body))
     assert declared == set(capi.EXPORTS), declared ^ set(capi.EXPORTS)
     L = capi.lib()
     for name in declared:
