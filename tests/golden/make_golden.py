@@ -449,6 +449,38 @@ def build_cases():
     cfg2['sources']['source']['intensity'] = 60000
     add('Q_ten_counts', 'counts', cfg2)
 
+    # --- edge cases: empty and tiny ray arrays, tile boundaries of the device kernels (256 rays), nothing
+    #     reaching the Bragg element, a single pixel, the largest scene the C ABI takes (16 optics) ------------
+    for n in (0, 1, 2, 255, 256, 257):
+        add('X_rays_%d_trace' % n, 'trace', cfg_three(n, dict(sph, rocking_fwhm=5e-3), history=True, seed=40 + n))
+    add('X_rays_1_counts', 'counts', cfg_three(1, dict(sph, rocking_fwhm=5e-3), seed=47, runs=5, iters=3))
+    add('X_all_lost_trace', 'trace', cfg_three(3000, dict(sph, xsize=1e-7, ysize=1e-7, rocking_fwhm=5e-3), history=True, seed=48))
+    add('X_all_lost_counts', 'counts', cfg_three(30000, dict(sph, origin=[0.5, 0.0, 0.80374151], rocking_fwhm=5e-3),
+                                                 seed=49, runs=2, iters=2))
+    add('X_one_pixel_trace', 'trace', cfg_three(3000, dict(sph, rocking_fwhm=5e-3, pixel_size=0.2), history=True, seed=50,
+                                                detector=_detector(pixel_size=0.4)))
+    cfg16 = copy.deepcopy(cfg)
+    optics = {}
+    for i in range(10):                                  # ten apertures of alternating shape in front of the crystal
+        z = 0.07 * (i + 1)
+        ap = [{'shape': 'circle', 'size': [0.02 + 0.011 * i]}, {'shape': 'square', 'size': [0.05 + 0.02 * i]}][i % 2]
+        optics['ap%d' % i] = {'class_name': 'XicsrtOpticAperture', 'origin': [0.0, 0.0, z], 'zaxis': [0.0, 0.0, -1.0],
+                              'xsize': 0.3, 'ysize': 0.3, 'aperture': [ap]}
+    optics['crystal'] = cfg['optics']['crystal']
+    for i, f in enumerate((0.2, 0.4, 0.6, 0.8)):
+        optics['out%d' % i] = {'class_name': 'XicsrtOpticAperture', 'origin': (crystal_at + f * (det_at - crystal_at)).tolist(),
+                               'zaxis': (-out_dir).tolist(), 'xsize': 0.5, 'ysize': 0.5,
+                               'aperture': [{'shape': 'circle', 'size': [0.05 - 0.006 * i]}]}
+    optics['detector'] = cfg['optics']['detector']
+    assert len(optics) == 16
+    cfg16['optics'] = optics
+    cfg16['general']['random_seed'] = 56
+    add('X_sixteen_trace', 'trace', cfg16)
+    cfg16c = copy.deepcopy(cfg16)
+    cfg16c['general'].update(keep_history=False, number_of_iter=2, number_of_runs=2)
+    cfg16c['sources']['source']['intensity'] = 50000
+    add('X_sixteen_counts', 'counts', cfg16c)
+
     # --- BASELINE.json configurations at their stated geometry, reference-sized run counts -----------------
     # cfg2: point source -> planar mirror -> detector, 1e6 rays per run
     add('B_cfg2_mirror_1e6', 'counts', cfg_three(1000000, mir, seed=81, runs=2))

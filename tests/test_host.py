@@ -319,3 +319,18 @@ def test_plasma_with_temperature_profile_and_linewidth_flattens():
     config, elements, flat = helpers.build(cfg)
     pl = flat.struct.source.plasma.contents
     assert pl.n_temperature > 0 and pl.voigt_gamma > 0.0 and pl.n_weideman == 40 and pl.weideman_L > 0.0
+
+
+def test_history_of_a_single_ray_does_not_alias_the_device_snapshot():
+    """With one ray the transposed [3, 1] blocks of the snapshot are contiguous already: the per-element
+    dictionaries must still be copies (the replay of the reference's masked updates edits them in place)."""
+    from xicsrt_amd import xicsrt_raytrace as xrt
+    rays = np.full((3, 8, 1), np.nan)
+    rays[0, :, 0] = [0, 0, 0, 0.1, 0.2, 0.97, 3.9, 1.0]
+    rays[1, :, 0] = [0.1, 0.2, 0.9, 0.1, 0.2, 0.97, 3.9, 1.0]        # lost at the second element
+    mask = np.array([[True], [False], [False]])
+    before = rays.copy()
+    hist = xrt._history_from_device(['source', 'crystal', 'detector'], rays, mask)
+    assert np.array_equal(np.isnan(before), np.isnan(rays)) and np.array_equal(before[~np.isnan(before)], rays[~np.isnan(rays)])
+    # later elements: NaN origin, direction as the ray had it when it was lost
+    assert np.all(np.isnan(hist['detector']['origin'])) and np.array_equal(hist['detector']['direction'][0], [0.1, 0.2, 0.97])

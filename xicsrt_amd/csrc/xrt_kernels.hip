@@ -1771,7 +1771,7 @@ extern "C" int xrt_scene_check(const xrt_scene_t* sc)
         if (o.interact == XRT_INTERACT_MOSAIC && sc->source.intensity >= (1ll << 29))
             return fail(-2, "%s", "mosaic crystals take at most 2^29 - 1 rays per iteration (three ray-index bits carry flags)");
         if (o.n_apertures < 0 || o.n_apertures > XRT_MAX_APERTURES) return fail(-2, "%s", "bad aperture count");
-        if ((o.flags & XRT_F_IMAGE) && (o.pixel_nx <= 0 || o.pixel_ny <= 0 || o.image_offset < 0 ||
+        if ((o.flags & XRT_F_IMAGE) && (o.pixel_nx < 0 || o.pixel_ny < 0 || o.image_offset < 0 ||      // (0 x n images exist: np.round(0.5) = 0)
                                         o.image_offset + (int64_t)o.pixel_nx * o.pixel_ny > sc->image_bins))
             return fail(-2, "%s", "image layout inconsistent");
     }

@@ -369,8 +369,9 @@ def _history_from_device(names, rays, mask, optics=None):
     prev_wl = None
     prev_mask = None
     for e, name in enumerate(names):
-        origin = np.ascontiguousarray(rays[e, 0:3, :].T)
-        direction = np.ascontiguousarray(rays[e, 3:6, :].T)
+        # (copies: with a single ray the transposed view is already contiguous and would alias `rays`)
+        origin = np.array(rays[e, 0:3, :].T, order='C', copy=True)
+        direction = np.array(rays[e, 3:6, :].T, order='C', copy=True)
         wavelength = rays[e, 6, :].copy()
         m = mask[e].copy()
         if e > 0:
@@ -744,8 +745,8 @@ def generate_rays_from_global_state(source_obj):
     device = DeviceTrace(flat)
     rays, mask, state_out = device.trace_history(_global_state(), keep_images=False)
     _set_global_state(state_out)
-    out = RayArray({'origin': np.ascontiguousarray(rays[0, 0:3, :].T),
-                    'direction': np.ascontiguousarray(rays[0, 3:6, :].T),
+    out = RayArray({'origin': np.array(rays[0, 0:3, :].T, order='C', copy=True),
+                    'direction': np.array(rays[0, 3:6, :].T, order='C', copy=True),
                     'wavelength': rays[0, 6, :].copy(),
                     'mask': mask[0].copy()})
     out['weight'] = rays[0, 7, :].copy()
