@@ -459,6 +459,18 @@ def build_cases():
                                                  seed=49, runs=2, iters=2))
     add('X_one_pixel_trace', 'trace', cfg_three(3000, dict(sph, rocking_fwhm=5e-3, pixel_size=0.2), history=True, seed=50,
                                                 detector=_detector(pixel_size=0.4)))
+    # degenerate parameters: a pencil beam, a fractional intensity, a Lorentzian only (temperature 0) and a
+    # Gaussian only line, a rocking curve of zero width, a crystal without bounds, a seed near 2^32
+    add('Y_spread_zero_trace', 'trace', cfg_three(300, dict(sph, rocking_fwhm=5e-3), source=_source(300, 0.0), history=True, seed=51))
+    add('Y_intensity_fraction_trace', 'trace', cfg_three(0, dict(sph, rocking_fwhm=5e-3), source=_source(777.9), history=True, seed=52))
+    add('Y_lorentz_only_trace', 'trace', cfg_three(0, sph, source=_source(1500, 10.0, linewidth=1.129e14, temperature=0.0,
+                                                                       mass_number=39.948), history=True, seed=53))
+    add('Y_step_zero_width_trace', 'trace', cfg_three(1500, dict(sph, rocking_type='step', rocking_fwhm=0.0), history=True, seed=54))
+    add('Y_gauss_zero_width_trace', 'trace', cfg_three(1500, dict(sph, rocking_fwhm=0.0), history=True, seed=54))
+    add('Y_big_seed_counts', 'counts', cfg_three(20000, dict(sph, rocking_fwhm=5e-3), seed=4294967290, runs=3, iters=2))
+    add('Y_seed_overflow_counts', 'counts', cfg_three(2000, dict(sph, rocking_fwhm=5e-3), seed=4294967290, runs=4))
+    add('Y_zero_iter_counts', 'counts', cfg_three(2000, dict(sph, rocking_fwhm=5e-3), seed=3, runs=2, iters=0))
+
     cfg16 = copy.deepcopy(cfg)
     optics = {}
     for i in range(10):                                  # ten apertures of alternating shape in front of the crystal

@@ -2,6 +2,7 @@
 CPU tests (-m "not gpu"): host-side logic of the drop-in boundary, the C ABI
 library's exports and static scene validation (no compute without a GPU).
 """
+import copy
 import ctypes as C
 import json
 import os
@@ -334,3 +335,37 @@ def test_history_of_a_single_ray_does_not_alias_the_device_snapshot():
     assert np.array_equal(np.isnan(before), np.isnan(rays)) and np.array_equal(before[~np.isnan(before)], rays[~np.isnan(rays)])
     # later elements: NaN origin, direction as the ray had it when it was lost
     assert np.all(np.isnan(hist['detector']['origin'])) and np.array_equal(hist['detector']['direction'][0], [0.1, 0.2, 0.97])
+
+
+@pytest.fixture
+def oracle_device(monkeypatch):
+    """raytrace() end to end on a machine without a GPU: helpers.OracleDeviceTrace stands in for the device."""
+    from xicsrt_amd import xicsrt_raytrace as xrt
+    monkeypatch.setattr(xrt, 'DeviceTrace', helpers.OracleDeviceTrace)
+    return xrt
+
+
+@pytest.mark.parametrize('name', ['X_rays_1_counts', 'X_all_lost_counts', 'X_sixteen_counts', 'Y_big_seed_counts'])
+def test_raytrace_entry_point_on_edge_cases(name, oracle_device):
+    """The host side of raytrace() (seed schedule, run loop, result dictionary) on the edge-case goldens."""
+    cfg, gold = helpers.load_golden(name)
+    res = oracle_device.raytrace(cfg)
+    for nm in res['total']['meta']:
+        assert int(res['total']['meta'][nm]['num_out']) == int(gold['num_out/' + nm]), nm
+    for nm, img in res['total']['image'].items():
+        if img is not None:
+            assert np.array_equal(np.asarray(img).astype(np.int64), gold['image/' + nm]), nm
+
+
+def test_raytrace_raises_what_the_reference_raises_for_degenerate_run_settings(oracle_device):
+    """xicsrt_raytrace.py:60-63 lets the triangular seed schedule run past 2^32 - 1 (np.random.seed then raises),
+    :114 divides by number_of_iter: both errors are part of the behaviour (goldens Y_seed_overflow / Y_zero_iter
+    record that the reference raised)."""
+    cfg, _ = helpers.load_golden('Y_big_seed_counts')
+    cfg = copy.deepcopy(cfg)
+    cfg['general'].update(number_of_runs=4)
+    with pytest.raises(ValueError, match=r'Seed must be between 0 and 2\*\*32 - 1'):
+        oracle_device.raytrace(cfg)
+    cfg['general'].update(number_of_runs=2, number_of_iter=0)
+    with pytest.raises(ZeroDivisionError):
+        oracle_device.raytrace(cfg)

@@ -143,14 +143,15 @@ class Elements:
 
 
 def run_seeds(random_seed, num_runs):
-    """Per-run seeds: cumulative increment, i.e. seed + i(i+1)/2 (xicsrt_raytrace.py:60-63)."""
+    """Per-run seeds: cumulative increment, i.e. seed + i(i+1)/2 (xicsrt_raytrace.py:60-63).  A schedule that
+    leaves np.random.seed's range raises what np.random.seed raises in the reference (:111)."""
     if random_seed is None:
         return [int.from_bytes(os.urandom(4), 'little') for _ in range(num_runs)]
     seeds = []
     s = random_seed
     for ii in range(num_runs):
         s += ii
-        seeds.append(int(s))
+        seeds.append(_check_seed(int(s)))
     return seeds
 
 
@@ -586,8 +587,10 @@ def _raytrace_runs(config, run_indices, seeds, internal, per_run_images=False):
     device = DeviceTrace(flat)
     my_seeds = [seeds[i] for i in run_indices]
     after_run = _RunImageWriter(config, device) if per_run_images else None
+    # evaluated whether or not histories are kept, as in the reference (raytrace_single :113-114):
+    # number_of_iter = 0 is a ZeroDivisionError there, and here
+    max_lost = _max_lost_iter(general, internal)
     if general['keep_history']:
-        max_lost = _max_lost_iter(general, internal)
         outputs = []
         for i, s in zip(run_indices, my_seeds):
             outputs.append((i, _run_with_history(config, elements, device, s, max_lost)))
