@@ -356,7 +356,9 @@ int xrt_make_image(const xrt_optic_t* optic, int64_t n, const double* rays, cons
  * device: -6 a plasma source produced more rays than the declared capacity; -7 a plasma bundle has an
  * intensity below one without Poisson statistics (the reference's ValueError,
  * _XicsrtSourceGeneric.py:193-194); -8 the candidate reserve of the Gaussian wavelength sampler was
- * exhausted (a > 8 sigma event).  0 = clean. */
+ * exhausted (a > 8 sigma event); -9 a per-bundle Voigt table without enough resolution (the reference's ValueError,
+ * tools/xicsrt_voigt.py); -10 a plasma source generated no ray at all in some iteration ("No rays generated",
+ * _XicsrtPlasmaGeneric.py:368-369).  0 = clean. */
 int xrt_check(void* workspace, void* stream);
 
 /* TraceObject.intersect / check_bounds / interact as separate calls on a caller's ray array

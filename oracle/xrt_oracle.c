@@ -629,6 +629,7 @@ static int64_t generate_rays(const xrt_source_t* s, mt_t* mt, rays_t* r)
         total += nb;
     }
     free(off);
+    if (total == 0) return -10;                                      /* 'No rays generated' (_XicsrtPlasmaGeneric.py:368-369) */
     return total;
 }
 

@@ -363,6 +363,18 @@ def build_cases():
     add('F_generic_plasma_trace', 'trace', cfg_three(0, sph, source=dict(box, class_name='XicsrtPlasmaGeneric',
                                                                         time_resolution=3e9), history=True, seed=69))
 
+    # plasma edge cases: a single bundle, point bundles, every bundle outside the sightline filter (no rays at all),
+    # small Poisson means (multiplication method) next to large ones (PTRS)
+    add('Z_plasma_one_bundle_trace', 'trace', cfg_three(0, sph, source=dict(p, bundle_count=1, bundle_volume=0.001, emissivity=2e15 / 50 / 40),
+                                                       history=True, seed=75))
+    add('Z_plasma_point_bundles_trace', 'trace', cfg_three(0, sph, source=dict(p, bundle_type='point'), history=True, seed=76))
+    cfg = cfg_three(0, sph, source=dict(box, filters=['sight'], emissivity=2e13), history=True, seed=77)
+    cfg['filters'] = {'sight': dict(flt['sight'], radius=1e-9)}
+    add('Z_plasma_all_filtered_trace', 'trace', cfg)
+    add('Z_plasma_small_means_counts', 'counts', cfg_three(0, dict(sph, rocking_fwhm=2e-3), source=dict(p, emissivity=2e15 / 50 / 300, bundle_count=400,
+                                                                                                     bundle_volume=0.001 / 400),
+                                                         seed=78, runs=2, iters=2))
+
     # --- the reference's own integrated tests (testing/integrated_test_01 / _02 .ipynb): one base config,
     #     crystal class swapped, non-strict config check with keys that most classes do not know ------------
     def integrated(radius, rmaj, rmin, fwhm, spread_deg, size, src_size, n):

@@ -296,6 +296,19 @@ def test_plasma_errors_surface_as_the_references_value_errors():
     cfg['general'].update(keep_history=False)
     with pytest.raises(ValueError, match='intensity of less than one encountered'):
         xicsrt_amd.raytrace(cfg)
+    # every bundle outside the sightline filter: the reference's generate_rays ends with 'No rays generated'
+    # (make_golden.py records that for Z_plasma_all_filtered_trace); fused route, staged route, history route
+    cfg, gold = helpers.load_golden('F_cubic_filter_trace')
+    cfg['filters']['sight']['radius'] = 1e-9
+    for history, staged in ((False, False), (False, True), (True, False)):
+        cfg['general'].update(keep_history=history)
+        if staged:
+            os.environ['XICSRT_PLASMA_STAGED'] = '1'
+        try:
+            with pytest.raises(ValueError, match='No rays generated. Check plasma input parameters'):
+                xicsrt_amd.raytrace(cfg)
+        finally:
+            os.environ.pop('XICSRT_PLASMA_STAGED', None)
 
 
 @pytest.mark.gpu

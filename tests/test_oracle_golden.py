@@ -95,3 +95,13 @@ def test_object_level_tracing_against_reference(name, oracle):
         assert np.max(np.abs(h[ok] - g[ok])) <= 1e-12 * np.max(np.abs(g[ok])), key
     assert np.array_equal(helpers.split_images(ext, images)['crystal'], gold['image'])
     assert helpers.state_next_double(st2) == float(gold['next_double'])
+
+
+def test_oracle_reports_a_plasma_without_rays():
+    """Every bundle outside the sightline filter: the reference's generate_rays raises 'No rays generated'
+    (recorded by make_golden.py for Z_plasma_all_filtered_trace); the oracle returns an error status."""
+    cfg, gold = helpers.load_golden('F_cubic_filter_trace')
+    cfg['filters']['sight']['radius'] = 1e-9
+    config, elements, flat = helpers.build(cfg)
+    with pytest.raises(AssertionError):
+        helpers.oracle_counts(flat, [int(config['general']['random_seed'])], 1)

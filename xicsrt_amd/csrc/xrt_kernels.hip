@@ -3032,6 +3032,8 @@ extern "C" int xrt_check(void* workspace, void* stream_)
         return fail(-9, "%s", "Voight CDF calculation does not have enough resolution or its domain is too small.");
     if (flags & 1u)
         return fail(-6, "%s", "plasma source produced more rays than the declared capacity (Poisson tail): results are truncated");
+    if (flags & 16u)
+        return fail(-10, "%s", "No rays generated. Check plasma input parameters");
     return 0;
 }
 

@@ -226,9 +226,9 @@ def raise_device_status(code, message):
     """Turn a device status (DeviceTrace.status) into the exception the reference raises for it."""
     if code == 0:
         return
-    if code in (-6, -7):
+    if code in (-6, -7, -10):
         # conditions the reference reports with ValueError while it builds the bundle sources
-        # (_XicsrtSourceGeneric.py:193-194, _XicsrtPlasmaGeneric.py:277-281)
+        # (_XicsrtSourceGeneric.py:193-194, _XicsrtPlasmaGeneric.py:277-281, :368-369)
         raise ValueError(message)
     from .capi import DeviceLibraryError
     raise DeviceLibraryError('xrt_check failed (%d): %s' % (code, message))
@@ -308,7 +308,7 @@ class DeviceTrace:
 
     def status(self):
         """(code, message) of the device status word of the calls issued so far (synchronises the stream);
-        code 0 = fine, -6 plasma ray capacity exceeded, -7 'intensity of less than one', -8 Gaussian
+        code 0 = fine, -6 plasma ray capacity exceeded, -7 'intensity of less than one', -10 'No rays generated', -8 Gaussian
         wavelength candidates exhausted (include/xicsrt_hip.h, xrt_check)."""
         if self._ws is None:
             return 0, ''
