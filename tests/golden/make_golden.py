@@ -434,6 +434,13 @@ def build_cases():
                      **dict(_BRAGG, check_bragg=False))
         tag = 'interp' if interp else 'flat'
         add('E_mesh_%s_trace' % tag, 'trace', cfg_three(500, c, history=True, seed=71))
+    # tiny and lopsided meshes: one quad (two faces) with the coarse level as fine as the fine one, a 3 x 2 grid,
+    # a coarse mesh finer than the fine mesh, many thin columns (the nearest-point buckets degenerate)
+    for tag, size, coarse, interp in (('2x2', [2, 2], [2, 2], False), ('3x2', [3, 2], [2, 2], True), ('coarse_finer', [4, 4], [9, 9], False),
+                                      ('61x3', [61, 3], [5, 5], True)):
+        c = _crystal('XicsrtOpticMeshToroidalCrystal', radius_major=1.0, radius_minor=0.2, mesh_size=size, mesh_coarse_size=coarse,
+                     mesh_interpolate=interp, **dict(_BRAGG, check_bragg=False))
+        add('E_mesh_tiny_%s_trace' % tag, 'trace', cfg_three(400, c, history=True, seed=79))
     # --- ten optics in a row (more than the eight the first device path could take): five apertures between
     #     the source and the crystal, the Bragg crystal, three apertures on the reflected beam, the detector
     cfg = cfg_three(4000, dict(sph, rocking_fwhm=2e-3), history=True, seed=55)
