@@ -401,6 +401,11 @@ def build_cases():
     # --- object-level API: generate_rays / trace_global / make_image on a caller's ray array ----
     add('O_object_sphere', 'object', cfg_three(4000, dict(sph, rocking_fwhm=2e-3), seed=91))
     add('O_object_mirror_local', 'object', cfg_three(3000, dict(mir, trace_local=True), seed=92))
+    # the caller switches every ray off / all but one off before trace_global (the Bragg element then draws 0 / <= 1 uniforms)
+    for tag in ('all_off', 'one_on'):
+        c = cfg_three(300, dict(sph, rocking_fwhm=5e-3), seed=93)
+        c['caller_mask'] = tag
+        add('O_object_sphere_' + tag, 'object', c)
     # the three steps of TraceObject.trace as separate calls
     add('O_steps_sphere', 'steps', cfg_three(3000, dict(sph, rocking_fwhm=2e-3), seed=93))
     add('O_steps_mirror_aperture', 'steps', cfg_three(3000, dict(mir, aperture=[{'shape': 'circle', 'size': [0.08]},
@@ -714,11 +719,18 @@ def run_object(cfg):
     """Object-level API: source.generate_rays(), some rays switched off by the caller, then
     optic.trace_global(rays) and optic.make_image(rays) (xicsrt_public.get_element objects)."""
     cfg = _ref_cfg(cfg)
+    off = cfg.pop('caller_mask', 'every_fifth_off')      # which rays the caller switches off: not a key of the config schema
     np.random.seed(cfg['general']['random_seed'])
     source = xicsrt.get_element(cfg, 'source')
     crystal = xicsrt.get_element(cfg, 'crystal')
     rays = source.generate_rays()
-    rays['mask'][::5] = False
+    if off == 'all_off':
+        rays['mask'][:] = False
+    elif off == 'one_on':
+        rays['mask'][:] = False
+        rays['mask'][7] = True
+    else:
+        rays['mask'][::5] = False
     out = {'names': np.array(['source', 'crystal'])}
     for k in ('origin', 'direction', 'wavelength', 'mask'):
         out['in/' + k] = np.array(rays[k])

@@ -206,16 +206,13 @@ def test_object_level_api_matches_reference(name):
     source = xicsrt_amd.get_element(cfg, 'source')
     crystal = xicsrt_amd.get_element(cfg, 'crystal')
     rays = source.generate_rays()
-    rays['mask'][::5] = False
-    assert np.array_equal(rays['mask'], gold['in/mask'])
+    assert np.all(rays['mask'])
+    rays['mask'][:] = gold['in/mask']                       # the caller switches rays off (every fifth / all / all but one)
     assert np.allclose(rays['direction'], gold['in/direction'], rtol=FLOAT_RTOL, atol=1e-16)
     rays = crystal.trace_global(rays)
     assert np.array_equal(rays['mask'], gold['out/mask'])
     for key in ('origin', 'direction', 'wavelength'):
-        g, h = gold['out/' + key], np.asarray(rays[key])
-        assert np.array_equal(np.isnan(h), np.isnan(g)), key
-        ok = ~np.isnan(g)
-        assert np.max(np.abs(h[ok] - g[ok])) <= FLOAT_RTOL * np.max(np.abs(g[ok])), key
+        _close(rays[key], gold['out/' + key], key)
     image = crystal.make_image(rays)
     assert image.dtype == np.float64 and np.array_equal(image, gold['image'])
     assert np.random.random_sample() == float(gold['next_double'])
