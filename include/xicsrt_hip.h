@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define XRT_ABI_VERSION 15
+#define XRT_ABI_VERSION 16
 
 #define XRT_MAX_OPTICS     16
 #define XRT_MAX_APERTURES  8
@@ -198,6 +198,13 @@ typedef struct xrt_source {
      * Rays with mask 0 do not take part (RayArray 'mask', objects/_RayArray.py:12-96). */
     const double*  ext_rays;
     const uint8_t* ext_mask;
+    /* XicsrtSourceGeneric.ray_filter (_XicsrtSourceGeneric.py:223, :393-396) for the non-plasma sources: the
+     * sightline filters attached to the source switch off (mask = False) the generated rays whose ORIGIN lies outside
+     * (filters/_XicsrtBundleFilterSightline.py:31-56 applied to the ray dictionary); the rays keep their places in
+     * the ray order and in the stream.  0: none. */
+    int32_t n_ray_filters;
+    int32_t pad_filters;
+    xrt_bundle_filter_t ray_filters[XRT_MAX_BUNDLE_FILTERS];
 } xrt_source_t;
 
 /* A triangulated-mesh surface (optics/_ShapeMesh.py:198-261 _mesh_precalc output), all HOST

@@ -595,6 +595,19 @@ static int64_t generate_rays(const xrt_source_t* s, mt_t* mt, rays_t* r)
     }
     if (s->kind != XRT_SRC_PLASMA) {
         generate_block(s, s->origin, mt, r, 0, r->n);
+        /* ray_filter (_XicsrtSourceGeneric.py:223, :393-396): XicsrtBundleFilterSightline.filter on the ray
+         * dictionary (filters/_XicsrtBundleFilterSightline.py:31-56): mask &= radius >= distance(origin, sightline) */
+        for (int f = 0; f < s->n_ray_filters; f++) {
+            const xrt_bundle_filter_t* F = &s->ray_filters[f];
+            for (int64_t i = 0; i < r->n; i++) {
+                double l0[3], l2[3];
+                for (int k = 0; k < 3; k++) l0[k] = F->origin[k] - r->o[3 * i + k];
+                const double proj = dot_e(F->zaxis, l0);
+                for (int k = 0; k < 3; k++) l2[k] = l0[k] - F->zaxis[k] * proj;
+                const double distance = sqrt(dot_e(l2, l2));
+                r->mask[i] = r->mask[i] && (F->radius >= distance);
+            }
+        }
         return r->n;
     }
     const int64_t B = s->bundle_count;
@@ -1310,9 +1323,10 @@ static int run_single(const xrt_scene_t* sc, mt_t* mtp, int n_iter,
         if (produced < 0) { rays_free(&r); return -3; }
         const int64_t stride = r.n;
         r.n = produced;
-        if (sc->source.kind == XRT_SRC_EXTERNAL) { for (int64_t i = 0; i < r.n; i++) num_out[0] += r.mask[i]; }
+        const int masked_source = sc->source.kind == XRT_SRC_EXTERNAL || sc->source.n_ray_filters > 0;
+        if (masked_source) { for (int64_t i = 0; i < r.n; i++) num_out[0] += r.mask[i]; }
         else num_out[0] += (uint64_t)r.n;
-        if (hist) save_history(&r, stride, 0, hist, hmask, sc->source.kind == XRT_SRC_EXTERNAL);
+        if (hist) save_history(&r, stride, 0, hist, hmask, masked_source);
         for (int e = 0; e < sc->n_optics; e++) {
             const xrt_optic_t* op = &sc->optics[e];
             trace_optic(op, &r, &mt);

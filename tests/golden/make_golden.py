@@ -363,6 +363,25 @@ def build_cases():
     add('F_generic_plasma_trace', 'trace', cfg_three(0, sph, source=dict(box, class_name='XicsrtPlasmaGeneric',
                                                                         time_resolution=3e9), history=True, seed=69))
 
+    # a sightline filter attached to an ordinary (extended) source: XicsrtSourceGeneric.ray_filter switches off the rays
+    # that start outside the sightline; they keep their places in the arrays and in the random stream
+    ext_src = _source(1500, 10.0, xsize=0.06, ysize=0.05, zsize=0.02, filters=['sight'])
+    ray_flt = {'sight': {'class_name': 'XicsrtBundleFilterSightline', 'origin': [0.004, -0.003, 0.8],
+                         'zaxis': [0.02, -0.01, -1.0], 'radius': 0.015}}
+    cfg = cfg_three(0, dict(sph, rocking_fwhm=5e-3), source=ext_src, history=True, seed=83)
+    cfg['filters'] = ray_flt
+    add('R_ray_filter_trace', 'trace', cfg)
+    cfg = cfg_three(0, dict(sph, rocking_fwhm=5e-3), source=dict(ext_src, intensity=40000, class_name='XicsrtSourceFocused',
+                                                                 target=[0.0, 0.0, 0.80374151]), seed=84, runs=2, iters=2)
+    cfg['filters'] = ray_flt
+    add('R_ray_filter_counts', 'counts', cfg)
+    cfg = cfg_three(0, dict(sph, rocking_fwhm=5e-3), source=ext_src, history=True, seed=85)
+    cfg['filters'] = {'sight': dict(ray_flt['sight'], radius=1e-9)}
+    add('R_ray_filter_all_off_trace', 'trace', cfg)
+    cfg = cfg_three(0, dict(sph, rocking_fwhm=5e-3), source=dict(ext_src, intensity=4000), seed=86, runs=2, iters=2, history=True)
+    cfg['filters'] = ray_flt
+    cfg['general']['history_max_lost'] = 300
+    add('H_history_ray_filter', 'history', cfg)
     # plasma edge cases: a single bundle, point bundles, every bundle outside the sightline filter (no rays at all),
     # small Poisson means (multiplication method) next to large ones (PTRS)
     add('Z_plasma_one_bundle_trace', 'trace', cfg_three(0, sph, source=dict(p, bundle_count=1, bundle_volume=0.001, emissivity=2e15 / 50 / 40),
@@ -666,7 +685,7 @@ def run_mesh_tables(cfg):
 
 def run_history(cfg):
     """xicsrt.raytrace with keep_history=True: totals + found / lost ray histories."""
-    cfg = copy.deepcopy(cfg)
+    cfg = _ref_cfg(cfg)
     res = xicsrt.raytrace(cfg)
     out = {}
     names = list(res['total']['meta'].keys())

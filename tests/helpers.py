@@ -116,7 +116,7 @@ def oracle_history(flat, state, all_rays=False):
     st = L.xrt_oracle_trace_history(flat.byref(), C.byref(state), num_out.ctypes.data, images.ctypes.data,
                                     rays.ctypes.data, mask.ctypes.data, C.byref(out))
     assert st == 0
-    if not all_rays:
+    if not all_rays and flat.struct.source.kind == xscene.SRC_KIND['plasma']:
         n = int(mask[0].sum())  # plasma sources: drawn ray count, n_rays is the capacity
     return num_out.astype(np.int64), images.astype(np.int64), rays[:, :, :n], mask[:, :n].astype(bool), out
 
@@ -201,7 +201,7 @@ class OracleDeviceTrace:
         state_out = (np.ctypeslib.as_array(out.key).copy(), int(out.pos), int(out.has_gauss), float(out.gauss))
         if on_device:
             return self.torch.from_numpy(rays.copy()), self.torch.from_numpy(mask.astype(np.uint8)), state_out
-        nn = rays.shape[2] if all_rays else int(mask[0].sum())
+        nn = int(mask[0].sum()) if (not all_rays and self.flat.struct.source.kind == xscene.SRC_KIND['plasma']) else rays.shape[2]
         return rays[:, :, :nn], mask[:, :nn], state_out
 
     def status(self):

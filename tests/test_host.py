@@ -161,11 +161,11 @@ def test_unsupported_scenes_fail_loudly():
     assert L.xrt_scene_check(flat.byref()) == 0
     flat.struct.source.plasma.contents.n_weideman = 0       # ... from coefficients that must be there
     assert L.xrt_scene_check(flat.byref()) != 0 and b'Weideman' in L.xrt_last_error()
-    cfg, gold = helpers.load_golden('C_sphere_trace')       # ray filters on a plain source
-    cfg['filters'] = {'sight': {'class_name': 'XicsrtBundleFilterSightline', 'radius': 0.1}}
-    cfg['sources']['source']['filters'] = ['sight']
-    with pytest.raises(NotImplementedError):
-        helpers.build(cfg)
+    cfg, gold = helpers.load_golden('R_ray_filter_trace')   # ray filters belong to the plain sources ...
+    config, elements, flat = helpers.build(cfg)
+    assert flat.struct.source.n_ray_filters == 1 and L.xrt_scene_check(flat.byref()) == 0
+    flat.struct.source.kind = xscene.SRC_KIND['plasma']      # ... a plasma filters its bundles
+    assert L.xrt_scene_check(flat.byref()) != 0
 
 
 def test_supported_scenes_validate():
@@ -175,7 +175,8 @@ def test_supported_scenes_validate():
                  'W_normal_trace', 'S_gaussian_spatial_trace', 'G_isotropic_xy_trace', 'Q_four_trace',
                  'P_local_trace', 'M_spherical_mosaic_cutoff_trace', 'F_plasma_trace', 'D_ToroidalCrystal_trace',
                  'E_mesh_flat_trace', 'E_mesh_interp_trace', 'E_mesh_sphere_trace', 'E_mesh_cylinder_trace',
-                 'M_mesh_mosaic_interp_trace', 'M_planar_mosaic_local_trace', 'F_toroidal_trace', 'F_datafile_filter_trace', 'F_spread_radius_trace', 'F_generic_plasma_trace'):
+                 'M_mesh_mosaic_interp_trace', 'M_planar_mosaic_local_trace', 'F_toroidal_trace', 'F_datafile_filter_trace', 'F_spread_radius_trace', 'F_generic_plasma_trace',
+                 'R_ray_filter_trace', 'X_sixteen_trace', 'E_mesh_tiny_2x2_trace'):
         cfg, gold = helpers.load_golden(name)
         config, elements, flat = helpers.build(cfg)
         assert L.xrt_scene_check(flat.byref()) == 0, (name, L.xrt_last_error())

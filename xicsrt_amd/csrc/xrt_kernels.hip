@@ -96,6 +96,8 @@ struct KSource {
     const KPlasma* plasma;      // device; per-bundle model or null
     const double*  ext_rays;    // XRT_SRC_EXTERNAL: [8][n_rays] device
     const uint8_t* ext_mask;
+    int32_t n_ray_filters, pad3;        // XicsrtSourceGeneric.ray_filter (staged path)
+    xrt_bundle_filter_t ray_filters[XRT_MAX_BUNDLE_FILTERS];
 };
 
 // Mesh tables live in global memory and are only ever read: typed pointers (address space 1 / 4) keep the
@@ -1741,6 +1743,9 @@ extern "C" int xrt_scene_check(const xrt_scene_t* sc)
     if (s.wavelength_dist < XRT_WL_CONST || s.wavelength_dist > XRT_WL_VOIGT)
         return fail(-2, "%s", "unknown wavelength_dist");
     if (s.kind < XRT_SRC_GENERIC || s.kind > XRT_SRC_EXTERNAL) return fail(-2, "%s", "unknown source kind");
+    if (s.n_ray_filters < 0 || s.n_ray_filters > XRT_MAX_BUNDLE_FILTERS) return fail(-2, "%s", "bad ray filter count");
+    if (s.n_ray_filters > 0 && (s.kind == XRT_SRC_PLASMA || s.kind == XRT_SRC_EXTERNAL))
+        return fail(-2, "%s", "ray filters belong to the non-plasma sources (a plasma filters its bundles)");
     if (s.kind == XRT_SRC_EXTERNAL && s.intensity > 0 && (!s.ext_rays || !s.ext_mask))
         return fail(-2, "%s", "external rays missing");
     if (s.kind == XRT_SRC_PLASMA) {
@@ -1836,6 +1841,7 @@ static bool needs_staged(const xrt_scene_t* sc)
 {
     const xrt_source_t& s = sc->source;
     if (s.kind == XRT_SRC_PLASMA || s.kind == XRT_SRC_EXTERNAL) return true;
+    if (s.n_ray_filters > 0) return true;                  // rays switched off at the source
     if (s.spatial_dist == XRT_SPATIAL_GAUSSIAN || s.angular_dist == XRT_ANG_ISOTROPIC_XY) return true;
     if (s.wavelength_dist == XRT_WL_NORMAL && !gauss_prepared(s)) return true;
     int n_bragg = 0;
@@ -2145,6 +2151,8 @@ static void build_kscene(const xrt_scene_t* sc, char* ws, KScene* k)
     d.bundle_intensity = s.bundle_intensity;
     d.use_poisson = s.use_poisson;
     d.ext_rays = s.ext_rays; d.ext_mask = s.ext_mask;
+    d.n_ray_filters = s.n_ray_filters;
+    for (int i = 0; i < XRT_MAX_BUNDLE_FILTERS; i++) d.ray_filters[i] = s.ray_filters[i];
     for (int i = 0; i < 3; i++) {
         const double low = -1.0 * s.plasma_size[i] / 2.0, high = s.plasma_size[i] / 2.0;
         d.plasma_low[i] = low; d.plasma_range[i] = high - low;

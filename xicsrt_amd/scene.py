@@ -20,7 +20,7 @@ import ctypes as C
 
 import numpy as np
 
-XRT_ABI_VERSION = 15
+XRT_ABI_VERSION = 16
 XRT_MAX_BUNDLE_FILTERS = 4
 XRT_MAX_OPTICS = 16
 XRT_MAX_APERTURES = 8
@@ -82,7 +82,9 @@ class Source(C.Structure):
                 ('bundle_count', C.c_int64), ('plasma_size', C.c_double * 3),
                 ('bundle_intensity', C.c_double), ('use_poisson', C.c_int32), ('pad_plasma', C.c_int32),
                 ('plasma', C.POINTER(Plasma)),
-                ('ext_rays', C.c_void_p), ('ext_mask', C.c_void_p)]
+                ('ext_rays', C.c_void_p), ('ext_mask', C.c_void_p),
+                ('n_ray_filters', C.c_int32), ('pad_filters', C.c_int32),
+                ('ray_filters', BundleFilter * XRT_MAX_BUNDLE_FILTERS)]
 
 
 _PD, _PI, _PB = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
@@ -391,8 +393,18 @@ def flatten_source(obj, out, keep):
     out.bundle_intensity = 0.0
     out.use_poisson = 0
     out.plasma = None
-    if obj.cone_axis_rule != 'plasma' and len(getattr(obj, 'filter_objects', [])) > 0:
-        raise SceneError('ray filters on a non-plasma source are not implemented on the device path')
+    out.n_ray_filters = 0
+    if obj.cone_axis_rule != 'plasma':
+        # XicsrtSourceGeneric.ray_filter: the attached filters act on the generated rays (their origins)
+        filters = [f for f in getattr(obj, 'filter_objects', []) if f.filter_kind != 'none']
+        if len(filters) > XRT_MAX_BUNDLE_FILTERS:
+            raise SceneError('more than %d filters on one source' % XRT_MAX_BUNDLE_FILTERS)
+        out.n_ray_filters = len(filters)
+        for i, f in enumerate(filters):
+            origin, zaxis, radius = f.sightline()
+            _vec(out.ray_filters[i].origin, origin)
+            _vec(out.ray_filters[i].zaxis, zaxis)
+            out.ray_filters[i].radius = float(radius)
     if obj.cone_axis_rule == 'plasma':
         q, B, lam, pl = plasma_as_source_param(obj, keep)
         if pl is not None:

@@ -302,7 +302,7 @@ class DeviceTrace:
         if on_device:
             return rays, mask, state_out
         mask_h = mask.cpu().numpy()[:, :n].astype(bool)
-        if not all_rays:
+        if not all_rays and self.flat.struct.source.kind == xscene.SRC_KIND['plasma']:
             n = int(mask_h[0].sum())    # plasma sources: the ray count is drawn, n_rays is the capacity
         return rays.cpu().numpy()[:, :, :n], mask_h[:, :n], state_out
 
@@ -420,7 +420,9 @@ def _sorted_history_from_device(elements, device, d_rays, d_mask, rng, max_lost)
     """
     t = device.torch
     mask_all = d_mask.cpu().numpy().astype(bool)
-    n = int(mask_all[0].sum())            # plasma sources: the ray count is drawn, the arrays hold the capacity
+    n = mask_all.shape[1]
+    if device.flat.struct.source.kind == xscene.SRC_KIND['plasma']:
+        n = int(mask_all[0].sum())        # plasma sources: the ray count is drawn, the arrays hold the capacity
     mask_h = mask_all[:, :n]
     last = mask_h[-1]
     w_found = np.flatnonzero(last)
