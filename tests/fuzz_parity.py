@@ -1,0 +1,95 @@
+"""Randomised parity sweep (not a test): device vs CPU oracle on random scenes drawn from everything the device
+path takes -- analytic and mesh optics, local frames, apertures, every source family incl. plasmas and sightline
+filters, several runs and iterations.  Counts and images must be equal exactly.
+python tests/fuzz_parity.py [cases] [first_seed]  ->  one JSON line per failure, a summary line at the end"""
+import sys, os, json, time, copy
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import logging
+logging.disable(logging.WARNING)
+import numpy as np, helpers
+from xicsrt_amd import xicsrt_raytrace as xrt
+import test_gpu_scale as scale
+
+CRYSTAL_AT = [0.0, 0.0, 0.80374151]
+ZAXIS = [0.0, 0.59497864, -0.80374151]
+
+
+def scene(rs):
+    cfg = scale._random_scene(rs)
+    cfg['sources']['source']['intensity'] = int(rs.choice([257, 5000, 40000, 150000]))
+    kind = rs.randint(6)
+    crystal = cfg['optics']['crystal']
+    bragg = dict(crystal_spacing=2.45676, rocking_type=['gaussian', 'step'][rs.randint(2)],
+                 rocking_fwhm=float(10 ** rs.uniform(-4.3, -2.0)))
+    if kind == 0:       # mesh crystals from the built-in generators
+        cls = ['XicsrtOpticMeshToroidalCrystal', 'XicsrtOpticMeshSphericalCrystal', 'XicsrtOpticMeshCylindricalCrystal'][rs.randint(3)]
+        c = {'class_name': cls, 'origin': CRYSTAL_AT, 'zaxis': ZAXIS, 'xsize': float(rs.uniform(0.05, 0.3)), 'ysize': float(rs.uniform(0.05, 0.3)),
+             'mesh_size': [int(rs.randint(2, 40)), int(rs.randint(2, 40))], 'mesh_coarse_size': [int(rs.randint(2, 9)), int(rs.randint(2, 9))],
+             'mesh_interpolate': bool(rs.randint(2)), 'check_bragg': bool(rs.randint(2))}
+        c.update(bragg)
+        if 'Toroidal' in cls:
+            c.update(radius_major=float(rs.uniform(0.9, 1.3)), radius_minor=float(rs.uniform(0.1, 0.4)))
+        else:
+            c['radius'] = float(rs.uniform(0.8, 1.5))
+        cfg['optics']['crystal'] = c
+        cfg['sources']['source']['intensity'] = int(rs.choice([257, 3000, 20000]))
+    elif kind == 1:     # analytic optic traced in its local frame
+        crystal['trace_local'] = True
+    elif kind == 2:     # plasma source
+        cfg['sources']['source'] = {
+            'class_name': ['XicsrtPlasmaCubic', 'XicsrtPlasmaToroidal'][rs.randint(2)], 'origin': [0.0, 0.0, 0.0],
+            'xsize': 0.1, 'ysize': 0.1, 'zsize': 0.1, 'target': CRYSTAL_AT, 'emissivity': float(rs.uniform(0.5, 8.0)) * 1e13,
+            'time_resolution': 1e-3, 'temperature': float(rs.uniform(200, 3000)), 'mass_number': 39.948,
+            'linewidth': float(rs.choice([0.0, 1.0e14])), 'wavelength': 3.9492, 'spread': float(np.radians(rs.uniform(0.5, 2.0))),
+            'use_poisson': True, 'bundle_count': int(rs.randint(20, 400)), 'bundle_volume': 1e-6, 'bundle_type': ['voxel', 'point'][rs.randint(2)]}
+        if 'Toroidal' in cfg['sources']['source']['class_name']:
+            cfg['sources']['source'].update(major_radius=0.08, minor_radius=0.05)
+    elif kind == 3:     # sightline filter on an extended ordinary source
+        cfg['sources']['source'].update(xsize=0.05, ysize=0.04, zsize=0.02, filters=['sight'])
+        cfg['filters'] = {'sight': {'class_name': 'XicsrtBundleFilterSightline', 'origin': [0.003, -0.002, 0.8],
+                                    'zaxis': [0.02, -0.01, -1.0], 'radius': float(rs.uniform(0.005, 0.03))}}
+    elif kind == 4:     # a second Bragg element in front of the detector
+        cfg['optics'] = {'crystal': crystal,
+                         'second': {'class_name': 'XicsrtOpticPlanarCrystal', 'origin': [0.0, 0.38, 0.69], 'zaxis': [0.0, -0.8, 0.6],
+                                    'xsize': 0.5, 'ysize': 0.5, 'check_bragg': bool(rs.randint(2)), **bragg},
+                         'detector': cfg['optics']['detector']}
+    return cfg
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
+    bad, skipped, paths, t0 = 0, 0, {}, time.time()
+    for case in range(n_cases):
+        rs = np.random.RandomState(seed0 + case)
+        cfg = scene(rs)
+        try:
+            config, elements, flat = helpers.build(copy.deepcopy(cfg))
+        except Exception as e:                      # a scene the host refuses (as the reference would, or out of scope)
+            skipped += 1
+            continue
+        g = config['general']
+        seeds = xrt.run_seeds(g['random_seed'], g['number_of_runs'])
+        try:
+            n_cpu, i_cpu = helpers.oracle_counts(flat, seeds, g['number_of_iter'], threads=8)
+        except AssertionError:                      # the oracle reports a condition the reference raises for
+            skipped += 1
+            continue
+        dev = xrt.DeviceTrace(flat)
+        dev.trace(seeds, g['number_of_iter'])
+        meta, image = dev.results()
+        n_gpu = np.array([int(meta[nm]['num_out']) for nm in flat.names])
+        i_gpu = dev.images.cpu().numpy()
+        key = cfg['optics']['crystal']['class_name'] + ' / ' + cfg['sources']['source']['class_name']
+        paths[key] = paths.get(key, 0) + 1
+        if not (np.array_equal(n_gpu, n_cpu) and np.array_equal(i_gpu[:flat.image_bins], i_cpu[:flat.image_bins])):
+            bad += 1
+            print(json.dumps({'case': seed0 + case, 'gpu': n_gpu.tolist(), 'oracle': [int(v) for v in n_cpu], 'config': cfg}), flush=True)
+        if case % 50 == 49:
+            print('# %d cases, %d mismatches, %.0f s' % (case + 1, bad, time.time() - t0), flush=True)
+    print(json.dumps({'cases': n_cases, 'first_seed': seed0, 'skipped': skipped, 'mismatches': bad, 'scenes': paths,
+                      'seconds': time.time() - t0}))
+
+
+if __name__ == '__main__':
+    main()
