@@ -75,6 +75,19 @@ def main():
         except AssertionError:                      # the oracle reports a condition the reference raises for
             skipped += 1
             continue
+        # the library reads its route switches at every call: draw some (segmented runs, small Bragg batches, ...)
+        env = {}
+        if rs.rand() < 0.4:
+            env['XICSRT_SEGMENTS'] = str(int(rs.choice([1, 2, 3, 7])))
+        if rs.rand() < 0.2:
+            env['XICSRT_BRAGG_BATCH_128'] = '1'
+        if rs.rand() < 0.1:
+            env['XICSRT_NO_JUMP'] = '1'
+        if rs.rand() < 0.1:
+            env['XICSRT_PLASMA_STAGED'] = '1'
+        for k in ('XICSRT_SEGMENTS', 'XICSRT_BRAGG_BATCH_128', 'XICSRT_NO_JUMP', 'XICSRT_PLASMA_STAGED'):
+            os.environ.pop(k, None)
+        os.environ.update(env)
         dev = xrt.DeviceTrace(flat)
         dev.trace(seeds, g['number_of_iter'])
         meta, image = dev.results()
@@ -84,7 +97,7 @@ def main():
         paths[key] = paths.get(key, 0) + 1
         if not (np.array_equal(n_gpu, n_cpu) and np.array_equal(i_gpu[:flat.image_bins], i_cpu[:flat.image_bins])):
             bad += 1
-            print(json.dumps({'case': seed0 + case, 'gpu': n_gpu.tolist(), 'oracle': [int(v) for v in n_cpu], 'config': cfg}), flush=True)
+            print(json.dumps({'case': seed0 + case, 'gpu': n_gpu.tolist(), 'oracle': [int(v) for v in n_cpu], 'env': env, 'config': cfg}), flush=True)
         if case % 50 == 49:
             print('# %d cases, %d mismatches, %.0f s' % (case + 1, bad, time.time() - t0), flush=True)
     print(json.dumps({'cases': n_cases, 'first_seed': seed0, 'skipped': skipped, 'mismatches': bad, 'scenes': paths,
