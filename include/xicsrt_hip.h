@@ -404,6 +404,7 @@ int xrt_selftest_div3(const double* num, const double* den, int64_t n, uint64_t*
 #define XRT_PATH_SEGMENTED     32u   /* runs split into segments (few runs of many rays)                */
 #define XRT_PATH_GAUSS_PREPARED 64u  /* np.random.normal wavelengths prepared as an array               */
 #define XRT_PATH_PLASMA_SCOUT 128u   /* plasma source: stream walked by one wave per run, rays rebuilt in the fused kernel */
+#define XRT_PATH_LDS_BINS     256u   /* fused kernel with the pixel bins pre-aggregated in LDS (image-heavy scenes without a Bragg test) */
 uint32_t xrt_last_path(int32_t reset);
 
 /* Diagnostic, host only: the MT19937 jump-ahead polynomial g(t) = t^J mod phi(t)

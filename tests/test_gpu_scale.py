@@ -207,11 +207,13 @@ def test_few_long_runs_are_segmented_and_equal_the_oracle():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('segments', ['4', '1'])
 @pytest.mark.parametrize('bragg', [False, True])
-def test_segmented_runs_chain_iterations(bragg, monkeypatch):
-    """Segmented runs over several iterations (the stream head a segmented iteration leaves must be the
-    one the next iteration's jump expects), with and without Bragg draws: equal to the oracle."""
-    monkeypatch.setenv('XICSRT_SEGMENTS', '4')
+def test_segmented_runs_chain_iterations(bragg, segments, monkeypatch):
+    """Segmented (4) and whole (1) runs over several iterations (the stream head an iteration leaves must be the
+    one the next iteration's jump expects), with and without Bragg draws (without: the kernel that counts its
+    pixels in LDS and never draws from the stream head): equal to the oracle."""
+    monkeypatch.setenv('XICSRT_SEGMENTS', segments)
     cfg = _spectrometer(20000, 2, seed=77, check_bragg=bragg, rocking_fwhm=3e-3)
     cfg['general']['number_of_iter'] = 3
     config, elements, flat = helpers.build(cfg)
@@ -270,9 +272,9 @@ def test_gaussian_wavelengths_with_a_cached_value_pending():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('env', ['XICSRT_NO_JUMP', 'XICSRT_NO_STAGE_SPLIT', 'XICSRT_STAGED_GAUSS', 'XICSRT_PLASMA_STAGED'])
+@pytest.mark.parametrize('env', ['XICSRT_NO_JUMP', 'XICSRT_NO_STAGE_SPLIT', 'XICSRT_STAGED_GAUSS', 'XICSRT_PLASMA_STAGED', 'XICSRT_NO_LDS_BINS'])
 @pytest.mark.parametrize('name', ['C_sphere_runs_iters', 'W_normal_1e5', 'F_plasma_counts', 'F_datafile_filter_counts',
-                                  'Q_four_counts', 'B_mirror_runs'])
+                                  'Q_four_counts', 'B_mirror_runs', 'A_example00_1e5', 'B_cfg2_mirror_1e6'])
 def test_alternative_device_paths_equal_reference(name, env, monkeypatch):
     """The library's fallbacks (sequential walk instead of jump-ahead, one-launch staged kernel, staged Gaussian
     wavelengths) are alternative routes to the same integers."""
@@ -311,6 +313,10 @@ def test_alternative_device_paths_equal_reference(name, env, monkeypatch):
         meta, image = dev2.results()
         forced_path = lib.xrt_last_path(1)
         assert (forced_path & capi.PATH_STAGED) and not (forced_path & capi.PATH_STAGE_SPLIT)
+    if env == 'XICSRT_NO_LDS_BINS':
+        # scenes without a Bragg test count their pixels in LDS first (when the bins fit); the switch sends them to the u64 bins directly
+        assert bool(default_path & capi.PATH_LDS_BINS) == name.startswith(('B_', 'A_'))
+        assert not (forced_path & capi.PATH_LDS_BINS)
     if env == 'XICSRT_STAGED_GAUSS' and (default_path & capi.PATH_GAUSS_PREPARED):
         assert (forced_path & capi.PATH_STAGED) and not (forced_path & capi.PATH_GAUSS_PREPARED)
     for nm in flat.names:
@@ -367,9 +373,12 @@ def _invariants(flat, seeds, parts, oracle_runs, threads=16):
 
 def test_cfg2_planar_mirror_1e8_photons():
     """BASELINE cfg2: point source -> planar mirror -> detector, 100 runs x 1e6 rays."""
+    from xicsrt_amd import capi
     config, elements, flat = helpers.build(_full_size('B_cfg2_mirror_1e6', 100))
     seeds = xrt.run_seeds(config['general']['random_seed'], 100)
+    capi.lib().xrt_last_path(1)
     n = _invariants(flat, seeds, parts=(7, 60), oracle_runs=8)
+    assert capi.lib().xrt_last_path(1) & capi.PATH_LDS_BINS           # pixel bins pre-aggregated in LDS
     assert int(n[0]) == 10 ** 8 and 0.51 < n[1] / n[0] < 0.53 and 0.31 < n[2] / n[0] < 0.325
     # the first two runs are the reference's own B_cfg2_mirror_1e6 job
     cfg, gold = helpers.load_golden('B_cfg2_mirror_1e6')
@@ -426,3 +435,23 @@ def test_plasma_runs_in_several_batches(monkeypatch):
     assert np.array_equal(n_one, n_many) and np.array_equal(i_one, i_many)
     n_cpu, i_cpu = helpers.oracle_counts(flat, seeds, 1, threads=8)
     assert np.array_equal(n_many, n_cpu) and np.array_equal(i_many[:flat.image_bins], i_cpu[:flat.image_bins])
+
+
+@pytest.mark.gpu
+def test_lds_pixel_bins_cannot_wrap():
+    """A pencil beam puts every ray of a run into one pixel: the 16-bit counters of the workgroup's LDS copy of the
+    bins are flushed before they can wrap (every 255 tiles), also across segments and runs."""
+    from xicsrt_amd import capi
+    cfg, _ = helpers.load_golden('A_example00_1e5')
+    cfg = copy.deepcopy(cfg)
+    cfg['general'].update(number_of_runs=3, number_of_iter=2)
+    cfg['sources']['source'].update(intensity=300000, spread=0.0)
+    config, elements, flat = helpers.build(cfg)
+    seeds = xrt.run_seeds(config['general']['random_seed'], 3)
+    capi.lib().xrt_last_path(1)
+    n_gpu, i_gpu = _trace(flat, seeds, n_iter=2)
+    assert capi.lib().xrt_last_path(1) & capi.PATH_LDS_BINS
+    assert int(n_gpu[0]) == 1800000 and int(n_gpu[1]) == 1800000
+    assert int(i_gpu[:flat.image_bins].max()) == 1800000 and int(i_gpu[:flat.image_bins].sum()) == 1800000
+    n_cpu, i_cpu = helpers.oracle_counts(flat, seeds, 2, threads=3)
+    assert np.array_equal(n_gpu, n_cpu) and np.array_equal(i_gpu[:flat.image_bins], i_cpu[:flat.image_bins])
