@@ -1,7 +1,7 @@
 """Randomised parity sweep (not a test): device vs CPU oracle on random scenes drawn from everything the device
 path takes -- analytic and mesh optics, local frames, apertures, every source family incl. plasmas and sightline
 filters, several runs and iterations.  Counts and images must be equal exactly.
-python tests/fuzz_parity.py [cases] [first_seed]  ->  one JSON line per failure, a summary line at the end"""
+python tests/fuzz_parity.py [--history] [cases] [first_seed]  ->  one JSON line per failure, a summary line at the end"""
 import sys, os, json, time, copy
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import logging
@@ -10,6 +10,9 @@ import numpy as np, helpers
 from xicsrt_amd import xicsrt_raytrace as xrt
 import test_gpu_scale as scale
 
+HISTORY = '--history' in sys.argv
+if HISTORY:
+    sys.argv.remove('--history')
 CRYSTAL_AT = [0.0, 0.0, 0.80374151]
 ZAXIS = [0.0, 0.59497864, -0.80374151]
 
@@ -95,7 +98,23 @@ def main():
         i_gpu = dev.images.cpu().numpy()
         key = cfg['optics']['crystal']['class_name'] + ' / ' + cfg['sources']['source']['class_name']
         paths[key] = paths.get(key, 0) + 1
-        if not (np.array_equal(n_gpu, n_cpu) and np.array_equal(i_gpu[:flat.image_bins], i_cpu[:flat.image_bins])):
+        ok = np.array_equal(n_gpu, n_cpu) and np.array_equal(i_gpu[:flat.image_bins], i_cpu[:flat.image_bins])
+        if ok and HISTORY and flat.n_rays <= 50000:
+            # one iteration with history from the first run's seed: masks equal, positions to 1e-9, same stream position after
+            devh = xrt.DeviceTrace(flat)
+            rays, mask, st = devh.trace_history(xrt.rng_state_from_seed(seeds[0]))
+            o_num, o_img, o_rays, o_mask, o_st = helpers.oracle_history(flat, helpers.seed_state(seeds[0]))
+            ok = rays.shape == o_rays.shape and np.array_equal(mask, o_mask) and np.array_equal(np.isnan(rays), np.isnan(o_rays))
+            if ok:
+                both = ~np.isnan(o_rays)
+                if both.any():
+                    # (1e-9: a lost ray that grazes the next plane is recorded hundreds of metres away, where last-ulp
+                    #  differences of the reflected direction show at 1e-11; the fixed tests hold the goldens to 1e-12)
+                    ok = np.max(np.abs(rays[both] - o_rays[both])) <= 1e-9 * max(1.0, float(np.max(np.abs(o_rays[both]))))
+                rs2 = np.random.RandomState(0)
+                rs2.set_state(('MT19937',) + tuple(st))
+                ok = ok and rs2.random_sample() == helpers.state_next_double(o_st)
+        if not ok:
             bad += 1
             print(json.dumps({'case': seed0 + case, 'gpu': n_gpu.tolist(), 'oracle': [int(v) for v in n_cpu], 'env': env, 'config': cfg}), flush=True)
         if case % 50 == 49:
