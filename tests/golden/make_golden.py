@@ -514,6 +514,20 @@ def build_cases():
     add('Y_seed_overflow_counts', 'counts', cfg_three(2000, dict(sph, rocking_fwhm=5e-3), seed=4294967290, runs=4))
     add('Y_zero_iter_counts', 'counts', cfg_three(2000, dict(sph, rocking_fwhm=5e-3), seed=3, runs=2, iters=0))
 
+    # found by tests/fuzz_parity.py: the z axes above, typed in with 8 digits, are 1.5e-9 short of unit length, the reference
+    # takes a plane's normal as it is (no division by its length in angle_calc), and with a STEP rocking curve a ray
+    # 1e-9 rad from the edge of the step then falls on the other side than with a unit normal
+    add('Y_step_edge_planar_counts', 'counts', {
+        'general': dict(_general(1667030425, runs=3, iters=2)),
+        'sources': {'source': {'class_name': 'XicsrtSourceGeneric', 'intensity': 150000, 'wavelength': 3.9492,
+                               'spread': 0.1394126057487311, 'xsize': 0.0, 'ysize': 0.0, 'zsize': 0.0,
+                               'linewidth': 112900000000000.0, 'temperature': 1000.0, 'mass_number': 39.948}},
+        'optics': {'crystal': {'class_name': 'XicsrtOpticPlanarCrystal', 'origin': [0.0, 0.0, 0.80374151],
+                               'zaxis': [0.0, 0.59497864, -0.80374151], 'xsize': 0.17608454490703235, 'ysize': 0.10534398864297627,
+                               'crystal_spacing': 2.45676, 'rocking_type': 'step', 'rocking_fwhm': 0.0001771938641382608,
+                               'reflectivity': 0.9136488535067315},
+                   'detector': _detector()}})
+
     cfg16 = copy.deepcopy(cfg)
     optics = {}
     for i in range(10):                                  # ten apertures of alternating shape in front of the crystal

@@ -115,6 +115,7 @@ struct KMesh {               // device pointers, see xrt_mesh_t
     int32_t n_points, n_faces, n_coarse_faces, interpolate, n_simplices, n_first;
     gdp faces_normal;
     const double* first_rec;        // [n_first + 1][10] p0, edge1, edge2 of the faces mesh_intersect_1 walks (coarse faces, or all)
+    const double* plane_rec;        // [n_first + 1][16] plane form of the same faces: n, n.p0, U, u0, V, v0, n.n (+inf: degenerate)
     const XRT_G1 d4v* face_rec;     // [n_faces] KFaceRec, read as four 32-byte vectors
     gip point_faces;                // [n_points][8] the faces around a point, -1 where the reference's mask is False
     gip ct_simplices, ct_neighbors;
@@ -719,7 +720,7 @@ __device__ __forceinline__ bool screen_df(const KOptic& op, double dfa, double t
 {
     decided = true;
     if (op.rocking_type == XRT_ROCKING_STEP) {
-        const double a = fabs(dfa), m = fma(op.half_fwhm, 1e-6, 1e-12);
+        const double a = fabs(dfa), m = fma(op.half_fwhm, 1e-5, 1e-12);
         if (a < op.half_fwhm - m) return op.reflectivity >= test;       // p = 1.0 * R exactly
         if (a > op.half_fwhm + m) return false;                         // p = 0.0 * R < test
     } else {
@@ -1636,7 +1637,7 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
                 } else {
                     // The reflection itself (exact normal: a square root and three divisions) waits until the
                     // survivors are drained, on dense lanes; here the screen decides nearly every candidate from
-                    // the incidence cosine alone, |d . nu| / (|nu| |d|) with the un-normalised normal direction nu.
+                    // the incidence cosine alone, |d . nu| / (|nu| |d|) with the un-normalised normal direction nu of a sphere.
                     if (have) {
                         q_load(q_wrap(qhead + vt), X, ray.d, ray.wl, id);
                         uint32_t n = spos + 2u * vt;
@@ -1644,7 +1645,9 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
                         bool decided = false;
                         V3 nu;
                         if (test > 0.0 && ((op.scr_ok && wl_shared) || op.scr2_ok) && normal_direction(op, X, nu)) {
-                            const double pp = dot_n(nu, nu) * dot_n(ray.d, ray.d);
+                            // (a plane's normal is the optic's z axis as the reference holds it -- |z| - 1 ~ 1e-9 for axes typed in
+                            //  with 8 digits -- and the reference does NOT divide by its length: neither does the screen)
+                            const double pp = (op.shape == XRT_SHAPE_PLANE ? 1.0 : dot_n(nu, nu)) * dot_n(ray.d, ray.d);
                             double y = __builtin_amdgcn_rsq(pp);
                             y = y * fma(-0.5 * pp * y, y, 1.5);
                             const double ca = fabs(dot_n(ray.d, nu)) * y;
@@ -1953,7 +1956,7 @@ static size_t mesh_bytes(const xrt_mesh_t* m)
     size_t b = al256(sizeof(KMesh));
     const size_t P = (size_t)m->n_points, F = (size_t)m->n_faces, Cn = (size_t)m->n_coarse_faces, T = (size_t)m->n_simplices;
     const size_t n_first = Cn > 0 ? Cn : F;
-    b += al256(F * 24) + al256((n_first + 1) * 80) + al256(F * sizeof(KFaceRec)) + al256(P * 32) + al256(P * 24);
+    b += al256(F * 24) + al256((n_first + 1) * 80) + al256((n_first + 1) * 128) + al256(F * sizeof(KFaceRec)) + al256(P * 32) + al256(P * 24);
     if (m->interpolate) b += 2 * al256(T * 3 * 4) + al256(T * 6 * 8) + al256(P * 2 * 8) + al256(4 * P * 8) + al256(8 * P * 8) + al256(P * 4);
     b += al256((2 * P + 1) * sizeof(KCellRec));                       // bucket grid: <= P buckets + <= P chained points
     return b;
@@ -2339,6 +2342,30 @@ static int upload_meshes(const xrt_scene_t* sc, char* ws, int n_runs, KScene* ks
                 for (int a = 0; a < 3; a++) { rec[10 * i + a] = q0[3 * i + a]; rec[10 * i + 3 + a] = q1[3 * i + a]; rec[10 * i + 6 + a] = q2[3 * i + a]; }
             k.n_first = (int32_t)n_first;
             k.first_rec = (const double*)put(rec.data(), rec.size() * 8);
+            // plane form of the same faces for the classification pass: P - p0 = u e1 + v e2 (+ w n), n = e1 x e2,
+            // u = (P - p0).U with U = (e2 x n) / (e1.(e2 x n)), v = (P - p0).V with V = (n x e1) / (e2.(n x e1))
+            std::vector<double> pr((n_first + 1) * 16, 0.0);
+            for (size_t i = 0; i <= n_first; i++) {
+                double* o = &pr[16 * i];
+                o[12] = HUGE_VAL;                                  // degenerate until shown otherwise (the spare record too)
+                if (i == n_first) break;
+                const double *p0 = q0 + 3 * i, *e1 = q1 + 3 * i, *e2 = q2 + 3 * i;
+                const double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+                const double a[3] = {e2[1] * n[2] - e2[2] * n[1], e2[2] * n[0] - e2[0] * n[2], e2[0] * n[1] - e2[1] * n[0]};   // e2 x n
+                const double b[3] = {n[1] * e1[2] - n[2] * e1[1], n[2] * e1[0] - n[0] * e1[2], n[0] * e1[1] - n[1] * e1[0]};   // n x e1
+                const double da = e1[0] * a[0] + e1[1] * a[1] + e1[2] * a[2], db = e2[0] * b[0] + e2[1] * b[1] + e2[2] * b[2];
+                const double nn = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+                bool ok = std::isfinite(nn) && nn > 0.0 && std::isfinite(da) && std::isfinite(db) && da != 0.0 && db != 0.0;
+                double U[3], V[3];
+                for (int c = 0; c < 3 && ok; c++) { U[c] = a[c] / da; V[c] = b[c] / db; ok = std::isfinite(U[c]) && std::isfinite(V[c]) && std::isfinite(p0[c]); }
+                if (!ok) continue;
+                o[0] = n[0]; o[1] = n[1]; o[2] = n[2]; o[3] = n[0] * p0[0] + n[1] * p0[1] + n[2] * p0[2];
+                o[4] = U[0]; o[5] = U[1]; o[6] = U[2]; o[7] = -(U[0] * p0[0] + U[1] * p0[1] + U[2] * p0[2]);
+                o[8] = V[0]; o[9] = V[1]; o[10] = V[2]; o[11] = -(V[0] * p0[0] + V[1] * p0[1] + V[2] * p0[2]);
+                o[12] = nn;
+                if (!std::isfinite(o[3]) || !std::isfinite(o[7]) || !std::isfinite(o[11])) { for (int c = 0; c < 12; c++) o[c] = 0.0; o[12] = HUGE_VAL; }
+            }
+            k.plane_rec = (const double*)put(pr.data(), pr.size() * 8);
         }
         {   // per face what the second pass reads, per point its <= 8 faces
             std::vector<KFaceRec> fr(F);
