@@ -1143,6 +1143,12 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
     int be = -1;
     for (int e = 0; e < SC.n_optics; e++)
         if (SC.opt[e].interact == XRT_INTERACT_CRYSTAL && (SC.opt[e].flags & XRT_F_CHECK_BRAGG)) be = e;
+    // A mesh crystal that makes the Bragg test: only the exhaustive first pass runs in a tile's own lanes (about half
+    // of a cone of rays misses the mesh altogether, and a wave of unrelated rays executes the union of its lanes'
+    // work); the rays that hit a face wait in the Bragg queue and get the rest -- nearest point, second pass,
+    // interpolation, bounds -- on the dense lanes of a Bragg batch, in ray order, just in front of their Bragg test.
+    bool mesh_pre = false;
+    if constexpr (EXT) mesh_pre = be >= 0 && SC.opt[be].shape == XRT_SHAPE_MESH;
 
     double wl_run = 0.0;        // the wavelength of every ray when it is not part of the records
     auto q_store = [&](uint32_t i, const V3& o, const V3& d, double wl, uint32_t id) __attribute__((always_inline)) {
@@ -1346,11 +1352,19 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
                                 ray.d = to_local(op.R, ray.d);
                             }
                             bool hit;
+                            if (is_mesh && e == be && mesh_pre && !counting) {
+                                // queued with its (local-frame) origin and the face of the first pass; see mesh_pre
+                                aux = mesh_first(op.mesh, ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z);
+                                hit = aux >= 0;
+                                X = ray.o;
+                                alive = hit;
+                            } else {
                             if (is_mesh) {
                                 const MeshHit h = mesh_hit(op.mesh, ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z);
                                 hit = h.hit != 0; X.x = h.x; X.y = h.y; X.z = h.z; aux = h.aux;
                             } else hit = intersect_point<FULL>(op, ray, X, false, pre0);
                             alive = hit && check_bounds<FULL>(op, X);
+                            }
                             if (HIST && !alive && !counting) {
                                 V3 xo = X, dd = ray.d;
                                 if (!hit) { xo.x = xo.y = xo.z = __builtin_nan(""); }
@@ -1601,14 +1615,43 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
                 const uint32_t vt = vtid();
                 have = vt < nb;
                 alive = false;
+                uint32_t n_draws = nb;       // Bragg uniforms the batch consumes: one per record (mesh_pre: per ray left)
                 if constexpr (EXT) {
                     const bool local = (op.flags & XRT_F_TRACE_LOCAL) != 0;
+                    uint32_t draw = vt;           // which of the batch's Bragg uniforms is this ray's
+                    int baux = 0;
                     if (have) {
                         q_load(q_wrap(qhead + vt), X, ray.d, ray.wl, id);
+                        baux = (int)qaux[q_wrap(qhead + vt)];
+                    }
+                    if (mesh_pre) {
+                        // the records are rays that hit a face in the first pass: the rest of ShapeMesh.intersect and the
+                        // bounds here, on dense lanes; the Bragg uniforms go to those that are left, in ray order
+                        bool cand = false;
+                        if (have) {
+                            ray.o = X;
+                            const MeshHit h = mesh_rest(op.mesh, ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z, baux);
+                            X.x = h.x; X.y = h.y; X.z = h.z; baux = h.aux;
+                            cand = (h.hit != 0) && check_bounds<FULL>(op, X);
+                            if (HIST && !cand) {
+                                V3 xo = X, dd = ray.d;
+                                if (h.hit == 0) { xo.x = xo.y = xo.z = __builtin_nan(""); }
+                                if (local) {
+                                    xo = to_external(op.R, xo);
+                                    xo.x += op.origin[0]; xo.y += op.origin[1]; xo.z += op.origin[2];
+                                    dd = to_external(op.R, dd);
+                                }
+                                hist_write(args.hist, args.hmask, N, be + 1, id, xo, dd, ray.wl, false);
+                            }
+                        }
+                        draw = wg_rank(cand, wave_tot, slot, tid, n_draws, rotw);
+                        have = cand;
+                    }
+                    if (have) {
                         V3 nrm;
-                        if (op.shape == XRT_SHAPE_MESH) nrm = mesh_normal(op.mesh, X.x, X.y, (int)qaux[q_wrap(qhead + vt)]);
+                        if (op.shape == XRT_SHAPE_MESH) nrm = mesh_normal(op.mesh, X.x, X.y, baux);
                         else nrm = surface_normal<FULL>(op, X);
-                        uint32_t n = spos + 2u * vt;
+                        uint32_t n = spos + 2u * draw;
                         double test = 0.0 + (1.0 - 0.0) * mt_double(stream[n & XRT_RMASK], stream[(n + 1u) & XRT_RMASK]);
                         alive = bragg_accept(op, ray, nrm, test, wl_shared, bragg_shared);
                         if (HIST && !alive) {
@@ -1662,8 +1705,8 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
                         if (alive) ray.o = X;
                     }
                 }
-                spos += 2u * nb;
-                s_used += 2ull * nb;
+                spos += 2u * n_draws;
+                s_used += 2ull * n_draws;
                 const uint32_t head_old = qhead;
                 qhead = q_wrap(qhead + nb);
                 qcount -= nb;
