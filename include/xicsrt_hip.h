@@ -327,7 +327,8 @@ size_t      xrt_workspace_bytes(const xrt_scene_t* scene, int32_t n_runs);
  *     images[0 .. scene->image_bins)  device u64, per-optic pixel counts
  * (the caller zeroes them; repeated calls accumulate, which is the reference's
  * combine_raytrace sum).  `images` may be NULL when keep_images is off.
- * Asynchronous on `stream` (a hipStream_t; NULL = default stream).
+ * Asynchronous on `stream` (a hipStream_t; NULL = default stream).  A scene with mesh optics first waits for the
+ * work already queued on `stream` (its packed mesh tables are copied into the workspace synchronously).
  */
 int xrt_trace(const xrt_scene_t* scene,
               const uint32_t* seeds, int32_t n_runs, int32_t n_iter,

@@ -2359,9 +2359,14 @@ static size_t plan_queue(const KScene& ks, int n_src_heads, bool ext, bool hist,
 static int upload_meshes(const xrt_scene_t* sc, char* ws, int n_runs, KScene* ks, hipStream_t stream)
 {
     char* base = ws + ws_off_staged(sc, n_runs) + staged_bytes(sc, n_runs);
+    bool synced = false;
     for (int e = 0; e < sc->n_optics; e++) {
         ks->opt[e].mesh = nullptr;
         if (sc->optics[e].shape != XRT_SHAPE_MESH) continue;
+        // The packed tables are host temporaries, copied synchronously; an earlier call on `stream` may still be
+        // reading this part of the workspace (with another layout): wait for it first.  (Mesh scenes only; every other
+        // call stays asynchronous.)
+        if (!synced) { HIP_TRY(hipStreamSynchronize(stream)); synced = true; }
         const xrt_mesh_t* m = sc->optics[e].mesh;
         KMesh k;
         memset(&k, 0, sizeof(k));
@@ -2482,7 +2487,6 @@ static int upload_meshes(const xrt_scene_t* sc, char* ws, int n_runs, KScene* ks
         ks->opt[e].mesh = reinterpret_cast<const KMesh*>(base);
         base += mesh_bytes(m);
     }
-    (void)stream;
     return 0;
 }
 
