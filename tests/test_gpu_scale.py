@@ -455,3 +455,34 @@ def test_lds_pixel_bins_cannot_wrap():
     assert int(i_gpu[:flat.image_bins].max()) == 1800000 and int(i_gpu[:flat.image_bins].sum()) == 1800000
     n_cpu, i_cpu = helpers.oracle_counts(flat, seeds, 2, threads=3)
     assert np.array_equal(n_gpu, n_cpu) and np.array_equal(i_gpu[:flat.image_bins], i_cpu[:flat.image_bins])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n_rays', [2500, 30000])
+@pytest.mark.parametrize('words', [1, 79, 111, 112, 400, 625])
+def test_history_from_any_generator_position(n_rays, words):
+    """xrt_trace_history from a numpy state whose position is anywhere in its block (what the lost-ray shuffle between
+    two iterations leaves): the fused kernel's heads read up to 112 words behind their position, which for pos < 112
+    lie in front of the imported block and are reconstructed by running MT19937 backwards.  Whole runs (2500 rays)
+    and segmented ones (30000), against the oracle.  (Found by tests/fuzz_raytrace.py.)"""
+    import ctypes as C
+    config, elements, flat = helpers.build(_spectrometer(n_rays, 1, seed=31, rocking_fwhm=3e-3))
+    rng = np.random.RandomState(31)
+    for _ in range(words):
+        rng.bytes(4)                                    # one 32-bit word each
+    st = rng.get_state()
+    assert st[2] == (words if words < 624 else words - 624)
+    state = helpers.xscene.RngState()
+    C.memmove(state.key, np.ascontiguousarray(st[1], dtype=np.uint32).ctypes.data, 624 * 4)
+    state.pos, state.has_gauss, state.gauss = int(st[2]), int(st[3]), float(st[4])
+    dev = xrt.DeviceTrace(flat)
+    dev._workspace(1)[0].fill_(0xA5)                    # nothing useful may be lying around in the workspace
+    rays, mask, st_out = dev.trace_history((st[1], st[2], st[3], st[4]))
+    o_num, o_img, o_rays, o_mask, o_st = helpers.oracle_history(flat, state)
+    assert np.array_equal(mask, o_mask)
+    assert np.array_equal(np.isnan(rays), np.isnan(o_rays))
+    both = ~np.isnan(o_rays)
+    assert np.max(np.abs(rays[both] - o_rays[both])) <= 1e-12
+    rs2 = np.random.RandomState(0)
+    rs2.set_state(('MT19937',) + tuple(st_out))
+    assert rs2.random_sample() == helpers.state_next_double(o_st)

@@ -862,11 +862,26 @@ __device__ __forceinline__ void hist_write(double* hist, uint8_t* hmask, int64_t
 // --------------------------------------------------------------------------
 
 
-// explicit numpy state -> stream (xrt_trace_history)
+// explicit numpy state -> stream (xrt_trace_history).  The heads of the fused kernel refill their rings in fixed
+// half-ring steps and for that read up to 112 words BEHIND a head's position: with `pos` < 112 those lie in front of the
+// imported block.  MT19937 runs backwards as well: s[n+624] = s[n+397] ^ twist(msb(s[n]) | low31(s[n+1])) gives the top bit
+// of s[n] and the low 31 bits of s[n+1], so every earlier word follows from later ones; the 400 free slots of the ring
+// are filled with them (they are the words numpy generated before this block whenever there was such a block).
+__device__ __forceinline__ uint32_t mt_untwist(uint32_t t)      // y with twist(y) = t, y = msb(s[n]) | low31(s[n+1])
+{
+    return (t & 0x80000000u) ? (((t ^ 0x9908b0dfu) << 1) | 1u) : (t << 1);
+}
+
 __global__ void xrt_import_state_kernel(const KState* in, KStream* out, KState* gauss_state)
 {
     for (int i = threadIdx.x; i < 624; i += blockDim.x) out->ring[i] = in->key[i];
+    __syncthreads();
     if (threadIdx.x == 0) {
+        for (int n = -1; n >= -400; n--) {
+            const uint32_t hi = mt_untwist(out->ring[(uint32_t)(n + 624) & XRT_RMASK] ^ out->ring[(uint32_t)(n + 397) & XRT_RMASK]);
+            const uint32_t lo = mt_untwist(out->ring[(uint32_t)(n + 623) & XRT_RMASK] ^ out->ring[(uint32_t)(n + 396) & XRT_RMASK]);
+            out->ring[(uint32_t)n & XRT_RMASK] = (hi & 0x80000000u) | (lo & 0x7fffffffu);
+        }
         out->gen = 624; out->next = (uint64_t)in->pos;
         gauss_state[0].has_gauss = in->has_gauss;
         gauss_state[0].gauss = in->gauss;
