@@ -20,7 +20,7 @@ ZAXIS = [0.0, 0.59497864, -0.80374151]
 def scene(rs):
     cfg = scale._random_scene(rs)
     cfg['sources']['source']['intensity'] = int(rs.choice([257, 5000, 40000, 150000]))
-    kind = rs.randint(6)
+    kind = rs.randint(7)
     crystal = cfg['optics']['crystal']
     bragg = dict(crystal_spacing=2.45676, rocking_type=['gaussian', 'step'][rs.randint(2)],
                  rocking_fwhm=float(10 ** rs.uniform(-4.3, -2.0)))
@@ -56,6 +56,19 @@ def scene(rs):
                          'second': {'class_name': 'XicsrtOpticPlanarCrystal', 'origin': [0.0, 0.38, 0.69], 'zaxis': [0.0, -0.8, 0.6],
                                     'xsize': 0.5, 'ysize': 0.5, 'check_bragg': bool(rs.randint(2)), **bragg},
                          'detector': cfg['optics']['detector']}
+    elif kind == 6:     # mosaic crystals (the staged path: whole arrays of draws per layer)
+        cls = ['XicsrtOpticPlanarMosaicCrystal', 'XicsrtOpticSphericalMosaicCrystal'][rs.randint(2)]
+        c = {'class_name': cls, 'origin': CRYSTAL_AT, 'zaxis': ZAXIS, 'xsize': float(rs.uniform(0.05, 0.3)), 'ysize': float(rs.uniform(0.05, 0.3)),
+             'mosaic_spread': float(np.radians(rs.uniform(0.05, 0.8))), 'mosaic_depth': int(rs.randint(1, 8)),
+             'check_bragg': bool(rs.rand() < 0.8), 'trace_local': bool(rs.rand() < 0.3)}
+        c.update(bragg)
+        c['rocking_fwhm'] = float(10 ** rs.uniform(-3.3, -2.0))
+        if 'Spherical' in cls:
+            c['radius'] = float(rs.uniform(0.8, 1.5))
+        if rs.rand() < 0.5:
+            c['mosaic_cutoff'] = float(10 ** rs.uniform(-3.5, -1.5))
+        cfg['optics']['crystal'] = c
+        cfg['sources']['source']['intensity'] = int(rs.choice([257, 3000, 20000]))
     return cfg
 
 
