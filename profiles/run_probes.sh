@@ -20,3 +20,4 @@ probe "" "tests/bench_staged.py"                        # np.random.normal wavel
 probe "XICSRT_STAGED_GAUSS=1" "tests/bench_staged.py"   # ... through the staged kernels
 probe "" "tests/bench_cfg5.py 1000 1000000 2"           # BASELINE cfg5 at full size, flat and interpolated mesh
 probe "" "tests/bench_mosaic.py"                        # mosaic crystal, 15 layers (staged path)
+probe "" "tests/bench_history.py"                       # raytrace(config) with keep_history, as notebooks call it
