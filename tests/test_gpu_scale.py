@@ -486,3 +486,24 @@ def test_history_from_any_generator_position(n_rays, words):
     rs2 = np.random.RandomState(0)
     rs2.set_state(('MT19937',) + tuple(st_out))
     assert rs2.random_sample() == helpers.state_next_double(o_st)
+
+
+@pytest.mark.gpu
+def test_runs_just_above_the_resident_workgroups_split_off_a_tail(monkeypatch):
+    """1100 runs on 1024 workgroup slots: the unsegmented launch leaves the last 76 runs to a second pass (segmented
+    route) instead of letting them hold a slot each for a whole run time; same integers either way, equal to the oracle."""
+    from xicsrt_amd import capi
+    cfg = _spectrometer(20000, 1100, seed=41, rocking_fwhm=3e-3)
+    cfg['general']['number_of_iter'] = 2
+    config, elements, flat = helpers.build(cfg)
+    seeds = xrt.run_seeds(41, 1100)
+    lib = capi.lib()
+    lib.xrt_last_path(1)
+    n_split, i_split = _trace(flat, seeds, 2)
+    assert lib.xrt_last_path(1) & capi.PATH_SEGMENTED
+    monkeypatch.setenv('XICSRT_NO_TAIL_SPLIT', '1')
+    n_whole, i_whole = _trace(flat, seeds, 2)
+    assert not (lib.xrt_last_path(1) & capi.PATH_SEGMENTED)
+    assert np.array_equal(n_split, n_whole) and np.array_equal(i_split, i_whole)
+    n_cpu, i_cpu = helpers.oracle_counts(flat, seeds, 2, threads=16)
+    assert np.array_equal(n_split, n_cpu) and np.array_equal(i_split[:flat.image_bins], i_cpu[:flat.image_bins])

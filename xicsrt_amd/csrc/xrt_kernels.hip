@@ -2582,9 +2582,16 @@ static int upload_scene(const KScene& ks, char* ws, hipStream_t stream)
 }
 static const KScene* device_scene(char* ws) { return reinterpret_cast<const KScene*>(ws + ws_off_scene()); }
 
+// Runs just above a multiple of the resident workgroups: a run is one sequential stream, so the last few would each
+// hold a workgroup slot for a full run time while the rest of the chip idles (1024 runs: 20.0 ms, 1025: 35.2 ms).
+// xrt_trace lets the unsegmented launch leave out such a tail (< 256 runs) and traces it as a call of its own, which
+// takes the segmented route.  t_tail: -1 not allowed here, 0 allowed (set to the number of runs left out), > 0 decided.
+static thread_local int t_tail = -1;
+
 template <bool HIST, int VARIANT, bool SEG = false>
-static int launch_variant(const KScene* ks, const KArgs& a, int n_runs, size_t lds, hipStream_t stream)
+static int launch_variant(const KScene* ks, const KArgs& a_in, int n_runs, size_t lds, hipStream_t stream, bool may_leave_tail = false)
 {
+    KArgs a = a_in;
 #ifdef XRT_DEV_ONLY_LEAN     // development builds: only the lean kernel is compiled (seconds instead of a minute)
     if constexpr (HIST || VARIANT != 0 || SEG) return fail(-3, "%s", "development build: lean kernel only");
     else {
@@ -2606,6 +2613,10 @@ static int launch_variant(const KScene* ks, const KArgs& a, int n_runs, size_t l
     int cus = c_cus, per_cu = c_per_cu;
     if (const char* cap = getenv("XICSRT_MAX_WG_PER_CU")) { int c = atoi(cap); if (c >= 1 && c < per_cu) per_cu = c; }
     int grid = cus * per_cu;
+    if (!SEG && !HIST && may_leave_tail && t_tail >= 0 && !env_on("XICSRT_NO_TAIL_SPLIT")) {
+        if (t_tail == 0 && n_runs > grid && (n_runs % grid) < 256) t_tail = n_runs % grid;
+        if (t_tail > 0) { n_runs -= t_tail; a.n_runs = n_runs; }
+    }
     const int units = SEG ? n_runs * a.n_seg : n_runs;
     if (grid > units) grid = units;
     if (grid < 1) grid = 1;
@@ -2926,14 +2937,14 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
     const size_t lds = plan_queue(ks, nh, variant == 2, hist, &a, variant == 4 ? (uint32_t)((sc->image_bins + 1) / 2) : 0u);
     if (variant == 4) {
         g_paths |= XRT_PATH_LDS_BINS;
-        return launch_variant<false, 4>(device_scene(ws), a, n_runs, lds, stream);
+        return launch_variant<false, 4>(device_scene(ws), a, n_runs, lds, stream, true);
     }
     if (hist) {
         if (variant == 2) return launch_variant<true, 2>(device_scene(ws), a, n_runs, lds, stream);
         return variant == 1 ? launch_variant<true, 1>(device_scene(ws), a, n_runs, lds, stream) : launch_variant<true, 0>(device_scene(ws), a, n_runs, lds, stream);
     }
-    if (variant == 2) return launch_variant<false, 2>(device_scene(ws), a, n_runs, lds, stream);
-    return variant == 1 ? launch_variant<false, 1>(device_scene(ws), a, n_runs, lds, stream) : launch_variant<false, 0>(device_scene(ws), a, n_runs, lds, stream);
+    if (variant == 2) return launch_variant<false, 2>(device_scene(ws), a, n_runs, lds, stream, true);
+    return variant == 1 ? launch_variant<false, 1>(device_scene(ws), a, n_runs, lds, stream, true) : launch_variant<false, 0>(device_scene(ws), a, n_runs, lds, stream, true);
 }
 
 // diagnostic: g(t) = t^J mod phi(t) as 624 words (bit j of word j/32 = g_j); host only
@@ -2944,14 +2955,10 @@ extern "C" int xrt_mt_jump_poly(uint64_t J, uint32_t* out624)
     return 0;
 }
 
-extern "C" int xrt_trace(const xrt_scene_t* sc, const uint32_t* seeds, int32_t n_runs, int32_t n_iter,
-                         uint64_t* num_out, uint64_t* images, void* workspace, size_t workspace_bytes, void* stream_)
+static int trace_runs(const xrt_scene_t* sc, const uint32_t* seeds, int32_t n_runs, int32_t n_iter,
+                      uint64_t* num_out, uint64_t* images, void* workspace, void* stream_, bool clear_status)
 {
-    int st = xrt_scene_check(sc);
-    if (st) return st;
-    if (n_runs <= 0 || n_iter <= 0) return 0;
-    if (!seeds || !num_out || !workspace) return fail(-1, "%s", "NULL argument");
-    if (workspace_bytes < xrt_workspace_bytes(sc, n_runs)) return fail(-4, "%s", "workspace too small");
+    int st = 0;
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     char* ws = reinterpret_cast<char*>(workspace);
     uint32_t* d_seeds = reinterpret_cast<uint32_t*>(ws + ws_off_seeds(sc));
@@ -2962,7 +2969,7 @@ extern "C" int xrt_trace(const xrt_scene_t* sc, const uint32_t* seeds, int32_t n
     HIP_TRY(hipGetLastError());
     st = upload_tables(sc, ws, stream);
     if (st) return st;
-    HIP_TRY(hipMemsetAsync(ws + 64, 0, 64, stream));           // status word
+    if (clear_status) HIP_TRY(hipMemsetAsync(ws + 64, 0, 64, stream));           // status word
     KScene ks;
     build_kscene(sc, ws, &ks);
     st = upload_meshes(sc, ws, n_runs, &ks, stream);
@@ -2982,6 +2989,23 @@ extern "C" int xrt_trace(const xrt_scene_t* sc, const uint32_t* seeds, int32_t n
         if (st) return st;
     }
     return 0;
+}
+
+extern "C" int xrt_trace(const xrt_scene_t* sc, const uint32_t* seeds, int32_t n_runs, int32_t n_iter,
+                         uint64_t* num_out, uint64_t* images, void* workspace, size_t workspace_bytes, void* stream_)
+{
+    int st = xrt_scene_check(sc);
+    if (st) return st;
+    if (n_runs <= 0 || n_iter <= 0) return 0;
+    if (!seeds || !num_out || !workspace) return fail(-1, "%s", "NULL argument");
+    if (workspace_bytes < xrt_workspace_bytes(sc, n_runs)) return fail(-4, "%s", "workspace too small");
+    // (see t_tail: the unsegmented launch may leave the last < 256 runs to a second pass over the same workspace)
+    t_tail = 0;
+    st = trace_runs(sc, seeds, n_runs, n_iter, num_out, images, workspace, stream_, true);
+    const int tail = t_tail;
+    t_tail = -1;
+    if (st || tail <= 0) return st;
+    return trace_runs(sc, seeds + (n_runs - tail), tail, n_iter, num_out, images, workspace, stream_, false);
 }
 
 extern "C" int xrt_trace_history(const xrt_scene_t* sc, const xrt_rng_state_t* state_in,
