@@ -490,13 +490,13 @@ def test_history_from_any_generator_position(n_rays, words):
 
 @pytest.mark.gpu
 def test_runs_just_above_the_resident_workgroups_split_off_a_tail(monkeypatch):
-    """1100 runs on 1024 workgroup slots: the unsegmented launch leaves the last 76 runs to a second pass (segmented
+    """1060 runs on 1024 workgroup slots: the unsegmented launch leaves the last 36 runs to a second pass (segmented
     route) instead of letting them hold a slot each for a whole run time; same integers either way, equal to the oracle."""
     from xicsrt_amd import capi
-    cfg = _spectrometer(20000, 1100, seed=41, rocking_fwhm=3e-3)
+    cfg = _spectrometer(200000, 1060, seed=41, rocking_fwhm=3e-3)       # (only runs of >= 2e5 rays are worth a second pass)
     cfg['general']['number_of_iter'] = 2
     config, elements, flat = helpers.build(cfg)
-    seeds = xrt.run_seeds(41, 1100)
+    seeds = xrt.run_seeds(41, 1060)
     lib = capi.lib()
     lib.xrt_last_path(1)
     n_split, i_split = _trace(flat, seeds, 2)

@@ -3000,7 +3000,8 @@ extern "C" int xrt_trace(const xrt_scene_t* sc, const uint32_t* seeds, int32_t n
     if (!seeds || !num_out || !workspace) return fail(-1, "%s", "NULL argument");
     if (workspace_bytes < xrt_workspace_bytes(sc, n_runs)) return fail(-4, "%s", "workspace too small");
     // (see t_tail: the unsegmented launch may leave the last < 256 runs to a second pass over the same workspace)
-    t_tail = 0;
+    // (a second pass costs about a millisecond of set-up: only where a run takes longer than that)
+    t_tail = sc->source.intensity >= 200000 ? 0 : -1;
     st = trace_runs(sc, seeds, n_runs, n_iter, num_out, images, workspace, stream_, true);
     const int tail = t_tail;
     t_tail = -1;
