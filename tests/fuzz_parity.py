@@ -69,6 +69,10 @@ def scene(rs):
             c['mosaic_cutoff'] = float(10 ** rs.uniform(-3.5, -1.5))
         cfg['optics']['crystal'] = c
         cfg['sources']['source']['intensity'] = int(rs.choice([257, 3000, 20000]))
+    if os.environ.get('FUZZ_MAX_ITER'):          # sweeps with longer chains of iterations / more runs per scene
+        cfg['general']['number_of_iter'] = int(rs.randint(1, int(os.environ['FUZZ_MAX_ITER']) + 1))
+    if os.environ.get('FUZZ_MAX_RUNS'):
+        cfg['general']['number_of_runs'] = int(rs.randint(1, int(os.environ['FUZZ_MAX_RUNS']) + 1))
     return cfg
 
 
