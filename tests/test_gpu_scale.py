@@ -11,6 +11,7 @@ import pytest
 import helpers
 from xicsrt_amd import config as xconfig
 from xicsrt_amd import xicsrt_raytrace as xrt
+from xicsrt_amd import capi
 
 pytestmark = pytest.mark.gpu
 
@@ -163,16 +164,26 @@ def test_random_scenes_equal_oracle(case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('route', ['one_pass', 'two_pass', 'parts', 'parts_two_pass', 'many_chunks'])
 @pytest.mark.parametrize('segments', ['3', '7'])
 @pytest.mark.parametrize('name', ['C_sphere_runs_iters', 'B_mirror_runs', 'C_sphere_2e5_s3', 'D_ToroidalCrystal_1e5',
                                   'E_mesh_interp_counts', 'A_example00_1e5', 'S_focused_1e5', 'W_voigt_1e5',
                                   'P_aperture_1e5', 'D_PlanarCrystal_bragg_1e5', 'G_flat_xy_5e4'])
-def test_segmented_runs_equal_reference(name, segments, monkeypatch):
-    """Runs split into segments (one work unit each, count pass + propagate pass, chunked Bragg stream)
-    give the reference's integers: golden num_out and images, several iterations included."""
+def test_segmented_runs_equal_reference(name, segments, route, monkeypatch):
+    """Runs split into work units -- segments with their own jump-positioned heads, parts of a segment that walk the
+    segment's heads to their rays -- give the reference's integers (golden num_out and images, several iterations
+    included) on both routes: one pass (candidates parked in HBM, stream offsets by look-back over the units in front)
+    and two passes (count, then propagate), with few and with many chunk heads in the Bragg stream."""
     if name not in helpers.golden_names('counts'):
         pytest.skip('no such golden')
     monkeypatch.setenv('XICSRT_SEGMENTS', segments)
+    if route in ('two_pass', 'parts_two_pass'):
+        monkeypatch.setenv('XICSRT_SEG_TWO_PASS', '1')
+    if route in ('parts', 'parts_two_pass'):
+        monkeypatch.setenv('XICSRT_SUBUNITS', '3')
+    if route == 'many_chunks':
+        monkeypatch.setenv('XICSRT_CHUNK_HEADS', '11')
+        monkeypatch.setenv('XICSRT_SUBUNITS', '2')
     cfg, gold = helpers.load_golden(name)
     config, elements, flat = helpers.build(cfg)
     g = config['general']
@@ -185,6 +196,10 @@ def test_segmented_runs_equal_reference(name, segments, monkeypatch):
     for nm in flat.names[1:]:
         if image[nm] is not None:
             assert np.array_equal(image[nm].astype(np.int64), gold['image/' + nm]), nm
+    path = capi.lib().xrt_last_path(1)
+    if path & capi.PATH_SEGMENTED:
+        has_bragg = any(o.interact == 2 and (o.flags & helpers.xscene.F_CHECK_BRAGG) for o in flat.struct.optics[:flat.struct.n_optics])
+        assert bool(path & capi.PATH_ONE_PASS) == (has_bragg and route not in ('two_pass', 'parts_two_pass')), (path, route)
 
 
 @pytest.mark.gpu

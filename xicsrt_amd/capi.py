@@ -21,6 +21,7 @@ EXPORTS = (
 PATH_FUSED, PATH_STAGED, PATH_STAGE_SPLIT, PATH_JUMP, PATH_SEEK, PATH_SEGMENTED, PATH_GAUSS_PREPARED = 1, 2, 4, 8, 16, 32, 64
 PATH_PLASMA_SCOUT = 128
 PATH_LDS_BINS = 256
+PATH_ONE_PASS = 512
 
 _lib = None
 

@@ -16,5 +16,5 @@ $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared \
     -mllvm -disable-machine-licm \
     -Wall -Wno-unused-function \
     ${XRT_EXTRA_FLAGS} \
-    -o libxicsrt_hip.so xrt_kernels.hip
-echo "built $(pwd)/libxicsrt_hip.so"
+    -o ${XRT_OUT:-libxicsrt_hip.so} xrt_kernels.hip
+echo "built $(pwd)/${XRT_OUT:-libxicsrt_hip.so}"

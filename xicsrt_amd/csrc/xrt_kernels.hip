@@ -825,8 +825,21 @@ __device__ __forceinline__ void image_hit_lds(const KOptic& op, const V3& X, uin
 // back-to-back scans need no second one.
 // --------------------------------------------------------------------------
 
+// Workgroup barrier for data that went through LDS only: waits for the wave's LDS operations, not for its
+// global loads / stores / atomics in flight (__syncthreads() does: a pixel atomic or a prefetched record in front of
+// a barrier then costs a round trip to L2 / HBM).  Used by the propagation kernel, whose waves talk through LDS.
+__device__ __forceinline__ void lds_barrier()
+{
+#ifdef XRT_FULL_BARRIERS
+    __syncthreads();
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
 // `rotw`: the ranks follow the virtual thread order (tid + 64 * rotw) mod 256, i.e. wave `rotw` holds
 // virtual threads 192.. and wave (4 - rotw) mod 4 comes first (see the wave rotation of the fused kernel).
+template <bool LDS_ONLY = false>
 __device__ __forceinline__ uint32_t wg_rank(bool flag, uint32_t* wave_tot /*[2][4]*/, int& slot,
                                             int tid, uint32_t& total, uint32_t rotw = 0u)
 {
@@ -835,7 +848,7 @@ __device__ __forceinline__ uint32_t wg_rank(bool flag, uint32_t* wave_tot /*[2][
     uint32_t wave = (((uint32_t)tid >> 6) + rotw) & 3u;
     uint32_t* wt = wave_tot + slot * 4;
     if ((tid & 63) == 0) wt[wave] = (uint32_t)__popcll(b);
-    __syncthreads();
+    if (LDS_ONLY) lds_barrier(); else __syncthreads();
     uint32_t t0 = wt[0], t1 = wt[1], t2 = wt[2], t3 = wt[3];
     uint32_t base = (wave > 0 ? t0 : 0u) + (wave > 1 ? t1 : 0u) + (wave > 2 ? t2 : 0u);
     total = uni32(t0 + t1 + t2 + t3);
@@ -928,6 +941,34 @@ __device__ __forceinline__ void wave_walk(uint32_t* ring, uint64_t& gen, uint64_
         }
         wave_fence();
         gen = target;
+    }
+}
+
+// The same walk over `count` words with 32-bit positions (inside the propagation kernel: a wave walks one ring)
+__device__ __forceinline__ void wave_walk_n(uint32_t* ring, uint32_t gen, uint64_t count, int lane)
+{
+    while (count >= 192ull) {
+        const uint32_t n0 = gen + (uint32_t)lane, n1 = n0 + 64u, n2 = n0 + 128u;
+        const uint32_t a0 = ring[(n0 - 624u) & XRT_RMASK], b0 = ring[(n0 - 623u) & XRT_RMASK], c0 = ring[(n0 - 227u) & XRT_RMASK];
+        const uint32_t a1 = ring[(n1 - 624u) & XRT_RMASK], b1 = ring[(n1 - 623u) & XRT_RMASK], c1 = ring[(n1 - 227u) & XRT_RMASK];
+        const uint32_t a2 = ring[(n2 - 624u) & XRT_RMASK], b2 = ring[(n2 - 623u) & XRT_RMASK], c2 = ring[(n2 - 227u) & XRT_RMASK];
+        ring[n0 & XRT_RMASK] = mt_mix(a0, b0, c0);
+        ring[n1 & XRT_RMASK] = mt_mix(a1, b1, c1);
+        ring[n2 & XRT_RMASK] = mt_mix(a2, b2, c2);
+        wave_fence();
+        gen += 192u; count -= 192ull;
+    }
+    if (count > 0ull) {
+        const uint32_t m = (uint32_t)count;
+#pragma unroll
+        for (uint32_t j = 0; j < 3; j++) {
+            const uint32_t o = j * 64u + (uint32_t)lane;
+            if (o < m) {
+                const uint32_t n = gen + o;
+                ring[n & XRT_RMASK] = mt_mix(ring[(n - 624u) & XRT_RMASK], ring[(n - 623u) & XRT_RMASK], ring[(n - 227u) & XRT_RMASK]);
+            }
+        }
+        wave_fence();
     }
 }
 
@@ -1036,6 +1077,25 @@ struct KArgs {
     const KStream* chunk_heads;         // per run n_seg stream heads, chunk_words apart, from the first Bragg uniform on
     int64_t  chunk_words;
     int64_t  run_stride;                // SEG: heads / chunk_heads of consecutive runs are this many KStreams apart
+    // A segment is shared by n_sub work units: all load the segment's heads, unit j first walks them (raw
+    // generation only) over the j * sub_len rays in front of its own
+    int32_t  n_sub, pad_sub;
+    int64_t  sub_len;
+    // SEG == 2 (one pass, look-back): every unit parks its Bragg candidates, stably compacted in ray order, in its part
+    // of the run's structure-of-arrays in HBM (record i of the unit at index ray_lo + i), publishes their number + 1 in
+    // unit_flag and, once the units in front of it in the run have published theirs, knows where its Bragg uniforms start
+    double*   cand;                     // [n_runs][6 or 7][cand_cap]
+    uint32_t* cand_id;                  // [n_runs][cand_cap] ray indices (HIST)
+    uint32_t* cand_aux;                 // [n_runs][cand_cap] hit face (variant 2)
+    int64_t   cand_cap;
+    uint32_t* unit_flag;                // [n_runs][n_seg * n_sub], zero before the launch
+    unsigned long long* dbg;            // development: [units][8] wall-clock stamps of a unit's phases (null: none)
+    // Pixel bins of the fused kernel: `images` may point to image_rep replicas, image_stride bins apart, which the library
+    // sums into the caller's bins behind the last launch.  Scattered 8-byte atomics execute at the memory side, and all
+    // workgroups adding into the same few hot pixels of a small image serialise there; workgroup w adds into replica w mod R.
+    uint32_t image_rep, pad_rep;
+    uint64_t image_stride;
+    unsigned long long* images_rep;     // host side: the replicas (launch_variant points `images` at them)
     // Gaussian wavelengths (np.random.normal) prepared by xrt_gauss_kernel: the values per run and ray, and
     // the words the rejection sampler consumed in front of the Bragg uniforms (null: none)
     const double*   wl_array;           // [n_runs][n_rays]
@@ -1073,11 +1133,15 @@ __device__ __forceinline__ const KScene* scene_fresh(const KScene* p)
 // cone, shared cone axis, constant or uniform wavelength, plane/sphere, no
 // apertures) with lower register use; 1: every source / analytic shape /
 // aperture feature; 2: 1 + optics traced in their local frame and mesh optics.
-// SEG: few runs of many rays -- the work unit is a segment of a run (see KArgs); the
-// Bragg uniform of a ray is indexed by its ordered live rank in the whole run, so a
-// first launch (mode 1) counts every unit's candidates and the second (mode 2) starts
-// each unit at the stream position the counts of the earlier segments give.
-template <bool HIST, int VARIANT, bool SEG>
+// SEG != 0: few runs of many rays -- the work unit is a part of a run (a segment, or one of the n_sub parts of a
+// segment; see KArgs).  The Bragg uniform of a ray is indexed by its ordered live rank in the whole run:
+//   SEG == 2 (one pass): a unit takes its rays up to the Bragg element once, parks the candidates in HBM (stably
+//     compacted, 48 - 60 B each), publishes their number and picks up the numbers of the units in front of it in the run
+//     (the dispenser hands units out in order, so those are always under way); that sum positions its stream head, and
+//     the unit runs the Bragg test and the elements behind it over its parked candidates;
+//   SEG == 1 (two passes; candidate buffers beyond the workspace budget): a first launch (mode 1) only counts every
+//     unit's candidates and the second (mode 2) starts each unit at the position the counts of the earlier units give.
+template <bool HIST, int VARIANT, int SEG>
 __global__ __launch_bounds__(XRT_TILE, (VARIANT == 2 ? 2 : XRT_WAVES_PER_EU))
 void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
 {
@@ -1113,29 +1177,31 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
     // bins in LDS instead, two 16-bit counters per word, and adds it to the u64 bins every 255 tiles (a counter grows
     // by at most 256 per tile) and at the end of its unit: 3.5 - 50 x fewer global atomics.
     uint32_t* lbins = bcast + 8;                                                        // [args.lbins_words]
+    unsigned long long* const img = args.images ? args.images + (size_t)(blockIdx.x % (args.image_rep ? args.image_rep : 1u)) * args.image_stride
+                                                : nullptr;
     uint32_t lb_tiles = 0;
     if constexpr (LBINS) {
         for (uint32_t i = (uint32_t)threadIdx.x; i < args.lbins_words; i += XRT_TILE) lbins[i] = 0u;
-        __syncthreads();
+        lds_barrier();
     }
     auto lbins_flush = [&]() __attribute__((always_inline)) {
         if constexpr (LBINS) {
-            __syncthreads();
+            lds_barrier();
             for (uint32_t i = (uint32_t)threadIdx.x; i < args.lbins_words; i += XRT_TILE) {
                 const uint32_t v = lbins[i];
                 if (v) {
                     lbins[i] = 0u;
-                    if (v & 0xffffu) atomicAdd(&args.images[2u * i], (unsigned long long)(v & 0xffffu));
-                    if (v >> 16) atomicAdd(&args.images[2u * i + 1u], (unsigned long long)(v >> 16));
+                    if (v & 0xffffu) atomicAdd(&img[2u * i], (unsigned long long)(v & 0xffffu));
+                    if (v >> 16) atomicAdd(&img[2u * i + 1u], (unsigned long long)(v >> 16));
                 }
             }
-            __syncthreads();
+            lds_barrier();
             lb_tiles = 0;
         }
     };
     auto pixel = [&](const KOptic& op, const V3& X) __attribute__((always_inline)) {
         if constexpr (LBINS) image_hit_lds(op, X, lbins);
-        else image_hit(op, X, args.images);
+        else image_hit(op, X, img);
     };
 
     // Fair sharing of a CU.  The SIMD arbiter prefers the oldest wave, so of the workgroups that share a CU the
@@ -1163,7 +1229,8 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
     // work); the rays that hit a face wait in the Bragg queue and get the rest -- nearest point, second pass,
     // interpolation, bounds -- on the dense lanes of a Bragg batch, in ray order, just in front of their Bragg test.
     bool mesh_pre = false;
-    if constexpr (EXT) mesh_pre = be >= 0 && SC.opt[be].shape == XRT_SHAPE_MESH;
+    // (SEG == 2 counts a unit's candidates in its first phase: the whole intersection runs there)
+    if constexpr (EXT && SEG != 2) mesh_pre = be >= 0 && SC.opt[be].shape == XRT_SHAPE_MESH;
 
     double wl_run = 0.0;        // the wavelength of every ray when it is not part of the records
     auto q_store = [&](uint32_t i, const V3& o, const V3& d, double wl, uint32_t id) __attribute__((always_inline)) {
@@ -1179,22 +1246,58 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
         id = HIST ? qid[i] : 0u;
     };
     auto q_wrap = [&](uint32_t i) __attribute__((always_inline)) -> uint32_t { return i >= qcap ? i - qcap : i; };
+    // SEG == 2: the same record in the run's candidate arrays in HBM (`cbase`: first double of the run's arrays)
+    double* cbase = nullptr;
+    size_t crun = 0;                // first ray-index / face word of the run
+    // (blocks of 256 records, component-major inside a block: what a batch reads lies in one 12 - 14 KB stretch)
+    const int q_ncomp = q_has_wl ? 7 : 6;
+    auto cand_store = [&](int64_t i, const V3& o, const V3& d, double wl, uint32_t id, int aux) __attribute__((always_inline)) {
+        double* c = cbase + (i >> 8) * (int64_t)(q_ncomp * 256) + (i & 255);
+        c[0 * 256] = o.x; c[1 * 256] = o.y; c[2 * 256] = o.z;
+        c[3 * 256] = d.x; c[4 * 256] = d.y; c[5 * 256] = d.z;
+        if (q_has_wl) c[6 * 256] = wl;
+        if (HIST) args.cand_id[crun + i] = id;
+        if (EXT) args.cand_aux[crun + i] = (uint32_t)aux;
+    };
+    auto cand_load = [&](int64_t i, V3& o, V3& d, double& wl, uint32_t& id, int& aux) __attribute__((always_inline)) {
+        const double* c = cbase + (i >> 8) * (int64_t)(q_ncomp * 256) + (i & 255);
+        o.x = c[0 * 256]; o.y = c[1 * 256]; o.z = c[2 * 256];
+        d.x = c[3 * 256]; d.y = c[4 * 256]; d.z = c[5 * 256];
+        wl = q_has_wl ? c[6 * 256] : wl_run;
+        id = HIST ? args.cand_id[crun + i] : 0u;
+        aux = EXT ? (int)args.cand_aux[crun + i] : 0;
+    };
 
     for (;;) {
         // ---- next run ------------------------------------------------------
         if (tid == 0) bcast[0] = atomicAdd(args.run_counter, 1u);
-        __syncthreads();
+        lds_barrier();
         const uint32_t unit = uni32(bcast[0]);
-        uint32_t run = unit, seg = 0;
-        if (SEG) { run = unit / (uint32_t)args.n_seg; seg = unit - run * (uint32_t)args.n_seg; }
+        uint32_t run = unit, seg = 0, sub = 0, upr = 1, uidx = 0;      // (upr: units per run, uidx: this unit's place in its run)
+        if (SEG) {
+            upr = (uint32_t)args.n_seg * (uint32_t)args.n_sub;
+            run = unit / upr; uidx = unit - run * upr;
+            seg = uidx / (uint32_t)args.n_sub; sub = uidx - seg * (uint32_t)args.n_sub;
+        }
         if (run >= (uint32_t)args.n_runs) break;
-        const bool counting = SEG && args.mode == 1;
+        const bool counting = SEG == 1 && args.mode == 1;
+        const bool last_unit = !SEG || uidx + 1u == upr;
+        if constexpr (SEG == 2) {
+            crun = (size_t)run * (size_t)args.cand_cap;
+            cbase = args.cand + crun * (size_t)q_ncomp;
+        }
         // a plasma run has as many rays as its bundles drew (xrt_plasma_scout_kernel), N is the capacity
         const bool plasma = FULL && !SEG && SRC.kind == XRT_SRC_PLASMA;
         const int64_t N_run = plasma ? (int64_t)uni64((uint64_t)args.plasma.n_src[run]) : N;
         // ray range of this unit
-        const int64_t ray_lo = SEG ? (int64_t)seg * args.seg_len : 0;
-        const int64_t ray_hi = SEG ? ((ray_lo + args.seg_len < N) ? ray_lo + args.seg_len : N) : N_run;
+        int64_t ray_lo = 0, ray_hi = N_run;
+        if (SEG) {
+            const int64_t seg_lo = (int64_t)seg * args.seg_len;
+            const int64_t seg_hi = (seg_lo + args.seg_len < N) ? seg_lo + args.seg_len : N;
+            ray_lo = seg_lo + (int64_t)sub * args.sub_len;
+            if (ray_lo > seg_hi) ray_lo = seg_hi;
+            ray_hi = (ray_lo + args.sub_len < seg_hi) ? ray_lo + args.sub_len : seg_hi;
+        }
 
         // ---- load the positioned heads and the stream head ----------------
         // The source heads advance in lockstep (512 words per tile each), so they share one position:
@@ -1218,7 +1321,7 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
                     h++;
                 }
             }
-            __syncthreads();
+            lds_barrier();
             // A head arrives with 0 (jump-ahead, sequential walk) to 624 words generated beyond its position;
             // each is brought to at least one tile's worth from where IT stands (its ring holds nothing older
             // than 1024 words behind its own front).
@@ -1241,7 +1344,7 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
                     }
                     if ((SRC.array_used >> k) & 1u) hh++;
                 }
-                __syncthreads();
+                lds_barrier();
             }
         }
         uint32_t hslot = 512u;      // slot of the current tile's first word, 0 or 512 (flipped when a tile starts)
@@ -1251,35 +1354,49 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
         // Bragg uniform, which lies 2 * (candidates of the earlier segments) words into the draws
         uint64_t seg_skip = 0;
         const KStream* st_in = st;
-        if (SEG && args.mode == 2 && (be >= 0 || seg + 1u == (uint32_t)args.n_seg)) {
-            // with a Bragg optic: the candidates of the earlier segments of this run, summed by the whole
-            // workgroup; without one only the last segment needs the stream (to store the run's new head).
-            // The draws start behind the source arrays (+ the words a Gaussian wavelength array consumed).
-            unsigned long long before = 0;
-            if (be >= 0) {
-                if (tid == 0) cnt[0] = 0ULL;
-                __syncthreads();
-                unsigned long long part = 0;
-                for (uint32_t q = (uint32_t)tid; q < seg; q += XRT_TILE) part += args.unit_count[(size_t)run * args.n_seg + q];
-                if (part) atomicAdd(&cnt[0], part);
-                __syncthreads();
-                before = uni64(cnt[0]);
-                __syncthreads();
+        uint64_t s_next0 = 0, s_gen0 = 0, s_used = 0;
+        uint32_t sgen = XRT_AHEAD, spos = 0;       // (until the head is opened: nothing to generate)
+        // (mt_step keeps XRT_AHEAD = 512 words generated beyond the stream head's position, and no more: the step in front of
+        //  a batch's survivor scan runs while slower waves still read the batch's 512 words, and a word's slot is that of the
+        //  word 1024 further on)
+        constexpr uint32_t s_ahead = XRT_AHEAD;
+        // Opens the unit's stream head.  SEG: `before` Bragg candidates of this run lie in front of the unit's; the draws
+        // start behind the source arrays (+ the words a Gaussian wavelength array consumed), at or behind a chunk head.
+        auto stream_open = [&](bool positioned, unsigned long long before) __attribute__((always_inline)) {
+            if (SEG && positioned) {
+                const uint64_t words = 2ull * before + (args.base_words ? uni64(args.base_words[run]) : 0ull);
+                const uint64_t chunk = words / (uint64_t)args.chunk_words;
+                seg_skip = words - chunk * (uint64_t)args.chunk_words;
+                st_in = args.chunk_heads + (size_t)run * args.run_stride + chunk;
             }
-            const uint64_t words = 2ull * before + (args.base_words ? uni64(args.base_words[run]) : 0ull);
-            const uint64_t chunk = words / (uint64_t)args.chunk_words;
-            seg_skip = words - chunk * (uint64_t)args.chunk_words;
-            st_in = args.chunk_heads + (size_t)run * args.run_stride + chunk;
+            if constexpr (!LBINS) for (int i = tid; i < (int)XRT_RING; i += XRT_TILE) stream[i] = st_in->ring[i];
+            s_next0 = uni64(st_in->next); s_gen0 = uni64(st_in->gen);
+            // (variant 4: nothing is drawn from the stream head, it passes through memory untouched and always counts as generated)
+            sgen = LBINS ? (uint32_t)s_next0 + XRT_AHEAD : (uint32_t)s_gen0; spos = (uint32_t)s_next0;
+        };
+        // SEG == 2 with a Bragg element: the head is opened behind the unit's first phase, when the units in front have
+        // published their candidate counts
+        const bool deferred = SEG == 2 && be >= 0;
+        if (!deferred) {
+            // SEG == 1, second launch, with a Bragg optic: the candidates of the earlier units of this run, summed by the
+            // whole workgroup.  Without a Bragg optic only the run's last unit needs the stream (to store the run's new head).
+            unsigned long long before = 0;
+            if (SEG == 1 && args.mode == 2 && be >= 0) {
+                if (tid == 0) cnt[0] = 0ULL;
+                lds_barrier();
+                unsigned long long part = 0;
+                for (uint32_t q = (uint32_t)tid; q < uidx; q += XRT_TILE) part += args.unit_count[(size_t)run * upr + q];
+                if (part) atomicAdd(&cnt[0], part);
+                lds_barrier();
+                before = uni64(cnt[0]);
+                lds_barrier();
+            }
+            stream_open(SEG != 0 && !counting && (be >= 0 || last_unit), before);
         }
-        if constexpr (!LBINS) for (int i = tid; i < (int)XRT_RING; i += XRT_TILE) stream[i] = st_in->ring[i];
-        const uint64_t s_next0 = uni64(st_in->next), s_gen0 = uni64(st_in->gen);
-        // (variant 4: nothing is drawn from the stream head, it passes through memory untouched and always counts as generated)
-        uint32_t sgen = LBINS ? (uint32_t)s_next0 + XRT_AHEAD : (uint32_t)s_gen0, spos = (uint32_t)s_next0;
-        uint64_t s_used = 0;
         uint32_t qhead = 0, qcount = 0, bcount = 0;
         uint32_t n_candidates = 0;
         if (tid < XRT_DEV_MAX_OPTICS + 1) cnt[tid] = 0ULL;
-        __syncthreads();
+        lds_barrier();
 
         // One generation step: every head (and the stream head) that has fewer
         // than 512 words ready extends its window by at most 227 words.  Steps
@@ -1303,8 +1420,8 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
                 gstep++;
             }
             uint32_t avail = sgen - spos;
-            if (avail < XRT_AHEAD) {
-                uint32_t chunk = XRT_AHEAD - avail;
+            if (avail < s_ahead) {
+                uint32_t chunk = s_ahead - avail;
                 if (chunk > 227u) chunk = 227u;
                 if ((uint32_t)tid < chunk) {
                     uint32_t n = sgen + (uint32_t)tid;
@@ -1315,14 +1432,40 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
             }
         };
 
-        if (SEG) {
-            // walk the stream head to this unit's first Bragg uniform (< chunk_words words)
-            while (seg_skip > 0) {
-                while ((sgen - spos) < XRT_AHEAD) { mt_step(); __syncthreads(); }
-                const uint32_t take = seg_skip < (uint64_t)XRT_AHEAD ? (uint32_t)seg_skip : XRT_AHEAD;
-                spos += take; s_used += take; seg_skip -= take;
+        // Walks the stream head to this unit's first Bragg uniform (seg_skip < chunk_words words) and, for a later part
+        // of a segment, the source heads over the `tiles` tiles of the parts in front.  Raw generation only, a wave per
+        // ring and without workgroup barriers (LDS operations of one wave execute in order; <= 227 words are independent,
+        // 192 = three per lane are produced per step), at raised issue priority: the walk is a chain of LDS round trips.
+        auto heads_skip = [&](int64_t tiles) __attribute__((always_inline)) {
+            if (seg_skip == 0 && tiles == 0) return;
+            lds_barrier();
+            __builtin_amdgcn_s_setprio(3);
+            const int wave = tid >> 6, lane = tid & 63;
+            if (tiles > 0) {
+                // (a head holds its words [0, 512) when a tile loop starts: word w in slot w & 1023)
+                for (int h = wave; h < nh; h += 4) wave_walk_n(rings + h * XRT_RING, XRT_AHEAD, 512ull * (uint64_t)tiles, lane);
+                hslot = (tiles & 1) ? 0u : 512u;
+                gstep = 3;
             }
-        }
+            if (seg_skip > 0) {
+                const uint32_t have = sgen - spos;          // words generated beyond the position
+                const uint64_t want = seg_skip + (uint64_t)XRT_AHEAD;
+                if (want > (uint64_t)have) {
+                    if (wave == 3) wave_walk_n(stream, sgen, want - (uint64_t)have, lane);
+                    sgen += (uint32_t)(want - (uint64_t)have);
+                }
+                spos += (uint32_t)seg_skip; s_used += seg_skip; seg_skip = 0;
+            }
+            __builtin_amdgcn_s_setprio(SEG == 2 ? 2 : 0);
+            lds_barrier();
+        };
+        auto stamp = [&](int k) __attribute__((always_inline)) {
+            if (SEG && args.dbg && tid == 0) args.dbg[(size_t)unit * 8 + k] = wall_clock64();
+        };
+        stamp(0);
+        if constexpr (SEG == 2) __builtin_amdgcn_s_setprio(2);       // (first phase: above the units in their second phase)
+        if (SEG) heads_skip((ray_lo < ray_hi) ? (int64_t)sub * (args.sub_len / XRT_TILE) : 0);
+        stamp(1);
 
         // A point source (no spatial array in use: every offset is -0 + 0 u = 0) has one origin per run;
         // it and what the first element derives from it alone are evaluated here instead of per ray
@@ -1439,7 +1582,7 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
                 // is found after it, on dense lanes
                 uint32_t n_out;
                 mt_step();
-                uint32_t rank = wg_rank(alive, wave_tot, slot, tid, n_out, rot_in);
+                uint32_t rank = wg_rank<true>(alive, wave_tot, slot, tid, n_out, rot_in);
                 (void)rank;
                 if (tid == 0 && !counting) cnt[e + 1] += n_out;
                 const bool image = (op.flags & XRT_F_IMAGE) && args.images && !counting;
@@ -1451,7 +1594,7 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
                 if (e + 1 < SC.n_optics && n_out > 0) {
                     if (alive) q_store(q_wrap(scratch + rank), ray.o, ray.d, ray.wl, id);
                     mt_step();
-                    __syncthreads();
+                    lds_barrier();
                     // the survivors move on to the waves behind the ones that held the incoming rays
                     rotw = (rotw + ((n_in + 63u) >> 6)) & 3u;
                     rot_in = rotw;
@@ -1480,7 +1623,7 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
             while (bcount >= 64u || (all && bcount > 0u)) {
                 const uint32_t n = bcount < 64u ? bcount : 64u;
                 mt_step();
-                __syncthreads();                                  // survivor records visible
+                lds_barrier();                                  // survivor records visible
                 scl = scene_fresh(scene_g);
                 const KOptic& opb = SC.opt[be];
                 const uint32_t vt = vtid();
@@ -1510,6 +1653,141 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
             }
         };
 
+        // ---- Bragg test of a batch (128 or 256) of candidates in ray order: the first nb records of the queue
+        auto bragg_batch = [&](uint32_t nb, bool drain_all) __attribute__((always_inline)) {
+            scl = scene_fresh(scene_g);
+            const KOptic& op = SC.opt[be];
+            // n uniforms from the stream head (np.random.uniform(0,1,n_live), optics/_InteractCrystal.py:189)
+            while ((sgen - spos) < 2u * nb) { mt_step(); lds_barrier(); }
+            mt_step();
+            lds_barrier();                                  // queue records visible
+            const uint32_t brot = rotw;
+            const uint32_t vt = vtid();
+            bool have = vt < nb, alive = false;
+            Ray ray;
+            V3 X;
+            uint32_t id = 0;
+            X.x = X.y = X.z = 0.0;
+            ray.o = X; ray.d = X; ray.wl = 0.0;
+            uint32_t n_draws = nb;       // Bragg uniforms the batch consumes: one per record (mesh_pre: per ray left)
+            if constexpr (EXT) {
+                const bool local = (op.flags & XRT_F_TRACE_LOCAL) != 0;
+                uint32_t draw = vt;           // which of the batch's Bragg uniforms is this ray's
+                int baux = 0;
+                if (have) {
+                    q_load(q_wrap(qhead + vt), X, ray.d, ray.wl, id);
+                    baux = (int)qaux[q_wrap(qhead + vt)];
+                }
+                if (mesh_pre) {
+                    // the records are rays that hit a face in the first pass: the rest of ShapeMesh.intersect and the
+                    // bounds here, on dense lanes; the Bragg uniforms go to those that are left, in ray order
+                    bool cand = false;
+                    if (have) {
+                        ray.o = X;
+                        const MeshHit h = mesh_rest(op.mesh, ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z, baux);
+                        X.x = h.x; X.y = h.y; X.z = h.z; baux = h.aux;
+                        cand = (h.hit != 0) && check_bounds<FULL>(op, X);
+                        if (HIST && !cand) {
+                            V3 xo = X, dd = ray.d;
+                            if (h.hit == 0) { xo.x = xo.y = xo.z = __builtin_nan(""); }
+                            if (local) {
+                                xo = to_external(op.R, xo);
+                                xo.x += op.origin[0]; xo.y += op.origin[1]; xo.z += op.origin[2];
+                                dd = to_external(op.R, dd);
+                            }
+                            hist_write(args.hist, args.hmask, N, be + 1, id, xo, dd, ray.wl, false);
+                        }
+                    }
+                    draw = wg_rank<true>(cand, wave_tot, slot, tid, n_draws, brot);
+                    have = cand;
+                }
+                if (have) {
+                    V3 nrm;
+                    if (op.shape == XRT_SHAPE_MESH) nrm = mesh_normal(op.mesh, X.x, X.y, baux);
+                    else nrm = surface_normal<FULL>(op, X);
+                    uint32_t n = spos + 2u * draw;
+                    double test = 0.0 + (1.0 - 0.0) * mt_double(stream[n & XRT_RMASK], stream[(n + 1u) & XRT_RMASK]);
+                    alive = bragg_accept(op, ray, nrm, test, wl_shared, bragg_shared);
+                    if (HIST && !alive) {
+                        V3 xo = X, dd = ray.d;
+                        if (local) {
+                            xo = to_external(op.R, xo);
+                            xo.x += op.origin[0]; xo.y += op.origin[1]; xo.z += op.origin[2];
+                            dd = to_external(op.R, dd);
+                        }
+                        hist_write(args.hist, args.hmask, N, be + 1, id, xo, dd, ray.wl, false);
+                    }
+                    if (alive) {
+                        ray.o = X;
+                        double dt = dot_e(ray.d, nrm);
+                        ray.d.x = ray.d.x - 2.0 * (dt * nrm.x);
+                        ray.d.y = ray.d.y - 2.0 * (dt * nrm.y);
+                        ray.d.z = ray.d.z - 2.0 * (dt * nrm.z);
+                        if (local) {
+                            ray.o = to_external(op.R, ray.o);
+                            ray.o.x += op.origin[0]; ray.o.y += op.origin[1]; ray.o.z += op.origin[2];
+                            ray.d = to_external(op.R, ray.d);
+                        }
+                        if (HIST) hist_write(args.hist, args.hmask, N, be + 1, id, ray.o, ray.d, ray.wl, true);
+                    }
+                }
+            } else {
+                // The reflection itself (exact normal: a square root and three divisions) waits until the
+                // survivors are drained, on dense lanes; here the screen decides nearly every candidate from
+                // the incidence cosine alone, |d . nu| / (|nu| |d|) with the un-normalised normal direction nu of a sphere.
+                if (have) {
+                    q_load(q_wrap(qhead + vt), X, ray.d, ray.wl, id);
+                    uint32_t n = spos + 2u * vt;
+                    double test = 0.0 + (1.0 - 0.0) * mt_double(stream[n & XRT_RMASK], stream[(n + 1u) & XRT_RMASK]);
+                    bool decided = false;
+                    V3 nu;
+                    if (test > 0.0 && ((op.scr_ok && wl_shared) || op.scr2_ok) && normal_direction(op, X, nu)) {
+                        // (a plane's normal is the optic's z axis as the reference holds it -- |z| - 1 ~ 1e-9 for axes typed in
+                        //  with 8 digits -- and the reference does NOT divide by its length: neither does the screen)
+                        const double pp = (op.shape == XRT_SHAPE_PLANE ? 1.0 : dot_n(nu, nu)) * dot_n(ray.d, ray.d);
+                        double y = __builtin_amdgcn_rsq(pp);
+                        y = y * fma(-0.5 * pp * y, y, 1.5);
+                        const double ca = fabs(dot_n(ray.d, nu)) * y;
+                        alive = (op.scr_ok && wl_shared) ? bragg_screen(op, ca, test, decided)
+                                                         : bragg_screen_wl(op, ca, ray.wl, test, decided);
+                    }
+                    if (!decided) alive = bragg_accept(op, ray, surface_normal<FULL>(op, X), test, wl_shared, bragg_shared);
+#if XRT_ABLATE == 1
+                    alive = alive && (id == 0xffffffffu);
+#endif
+                    if (HIST && !alive) hist_write(args.hist, args.hmask, N, be + 1, id, X, ray.d, ray.wl, false);
+                    if (alive) ray.o = X;
+                }
+            }
+            spos += 2u * n_draws;
+            s_used += 2ull * n_draws;
+            const uint32_t head_old = qhead;
+            qhead = q_wrap(qhead + nb);
+            qcount -= nb;
+            // ---- the reflected rays join the survivor queue, which sits right below the candidates' head:
+            // [qhead - bcount, qhead).  The batch just freed [head_old, qhead); the new survivors go to its
+            // upper end by ordered rank, and the (< 64) survivors left from earlier batches are moved up
+            // behind them by a wave that has nothing else to do in this stage (virtual wave 3): it reads
+            // them in front of the scan's barrier and writes them behind it.
+            V3 mo, md;
+            double mwl = 0.0;
+            uint32_t mid = 0;
+            mo.x = mo.y = mo.z = 0.0; md = mo;
+            const bool mover = (vt >= 192u) && (vt - 192u < bcount);
+            if (mover) q_load(q_wrap(head_old + qcap - bcount + (vt - 192u)), mo, md, mwl, mid);
+            uint32_t n_s;
+            mt_step();
+            const uint32_t srank = wg_rank<true>(alive, wave_tot, slot, tid, n_s, brot);
+            if (tid == 0) cnt[be + 1] += n_s;
+            if (alive) q_store(q_wrap(qhead + qcap - n_s + srank), ray.o, ray.d, ray.wl, id);
+            if (mover && n_s < nb) q_store(q_wrap(qhead + qcap - n_s - bcount + (vt - 192u)), mo, md, mwl, mid);
+            bcount += n_s;
+            rotw = (rotw + ((nb + 63u) >> 6)) & 3u;
+            // ---- survivors: 64 at a time (everything that is left behind the run's last batch) through
+            // the elements behind the Bragg element, on one full wave
+            drain_survivors(drain_all);
+        };
+
         // ---- tiles of 256 rays in original order ----------------------------
         for (int64_t i0 = ray_lo; i0 < ray_hi; i0 += XRT_TILE) {
             const int64_t left = ray_hi - i0;
@@ -1526,17 +1804,19 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
                     bcast[1] = ahead > 48 ? 0u : (ahead < -48 ? 2u : 1u);
                 }
                 if ((tiles_done & 31u) == 1u && tiles_done > 32u) {       // (a barrier lies between the two)
+                    // (one-pass units: a step higher, above the units that are in their second phase and wait for the first
+                    //  phase of the ones in front of them)
                     const uint32_t pr = uni32(bcast[1]);
-                    if (pr == 0u) __builtin_amdgcn_s_setprio(0);
-                    else if (pr == 1u) __builtin_amdgcn_s_setprio(1);
-                    else __builtin_amdgcn_s_setprio(2);
+                    if (pr == 0u) __builtin_amdgcn_s_setprio(SEG == 2 ? 1 : 0);
+                    else if (pr == 1u) __builtin_amdgcn_s_setprio(SEG == 2 ? 2 : 1);
+                    else __builtin_amdgcn_s_setprio(SEG == 2 ? 3 : 2);
                 }
                 tiles_done++;
             }
 
             // everything this tile consumes must be generated: normally already
             // done behind the previous tile's barriers
-            while (gstep < 3u) { mt_step(); __syncthreads(); }
+            while (gstep < 3u) { mt_step(); lds_barrier(); }
             hslot ^= 512u;
 
             double u[6];
@@ -1589,7 +1869,7 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
                 if (stop >= 0) {
                     uint32_t n_a;
                     mt_step();
-                    wg_rank(alive, wave_tot, slot, tid, n_a);
+                    wg_rank<true>(alive, wave_tot, slot, tid, n_a);
                     n_candidates += n_a;
                 }
                 continue;
@@ -1605,161 +1885,354 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
                 const uint32_t rot_here = (stop > 0) ? rotw : 0u;
                 uint32_t n_a;
                 mt_step();
-                uint32_t rank = wg_rank(alive, wave_tot, slot, tid, n_a, rot_here);
-                if constexpr (EXT) {
+                uint32_t rank = wg_rank<true>(alive, wave_tot, slot, tid, n_a, rot_here);
+                if constexpr (SEG == 2) {
+                    if (alive) cand_store(ray_lo + (int64_t)(n_candidates + rank), X, ray.d, ray.wl, id, aux);
+                    n_candidates += n_a;
+                } else if constexpr (EXT) {
                     if (alive) {
                         q_store(q_wrap(qhead + qcount + rank), X, ray.d, ray.wl, id);
                         qaux[q_wrap(qhead + qcount + rank)] = (uint32_t)aux;
                     }
+                    qcount += n_a;
                 } else {
                     if (alive) q_store(q_wrap(qhead + qcount + rank), X, ray.d, ray.wl, id);
+                    qcount += n_a;
                 }
-                qcount += n_a;
             }
 
             // ---- Bragg test, a batch (128 or 256) of queued rays at a time ------------------
-            const bool last_tile = (i0 + XRT_TILE >= ray_hi);
-            while (be >= 0 && (qcount >= bbatch || (last_tile && qcount > 0u))) {
-                scl = scene_fresh(scene_g);
-                const KOptic& op = SC.opt[be];
-                const uint32_t nb = qcount < bbatch ? qcount : bbatch;
-                // n uniforms from the stream head (np.random.uniform(0,1,n_live), optics/_InteractCrystal.py:189)
-                while ((sgen - spos) < 2u * nb) { mt_step(); __syncthreads(); }
-                mt_step();
-                __syncthreads();                                  // queue records visible
-                const uint32_t vt = vtid();
-                have = vt < nb;
-                alive = false;
-                uint32_t n_draws = nb;       // Bragg uniforms the batch consumes: one per record (mesh_pre: per ray left)
-                if constexpr (EXT) {
-                    const bool local = (op.flags & XRT_F_TRACE_LOCAL) != 0;
-                    uint32_t draw = vt;           // which of the batch's Bragg uniforms is this ray's
-                    int baux = 0;
-                    if (have) {
-                        q_load(q_wrap(qhead + vt), X, ray.d, ray.wl, id);
-                        baux = (int)qaux[q_wrap(qhead + vt)];
+            if constexpr (SEG != 2) {
+                const bool last_tile = (i0 + XRT_TILE >= ray_hi);
+                while (be >= 0 && (qcount >= bbatch || (last_tile && qcount > 0u))) {
+                    const uint32_t nb = qcount < bbatch ? qcount : bbatch;
+                    bragg_batch(nb, last_tile && qcount == nb);
+                }
+                if (be >= 0 && last_tile) drain_survivors(true);
+            }
+        }
+
+        // ---- SEG == 2: the unit's parked candidates.  Publish their number, wait for the numbers of the units in front
+        // (handed out earlier by the dispenser: under way or done, and waiting for nothing behind them), open the stream
+        // head at the position their sum gives, then Bragg test + the elements behind it, a batch at a time.
+        if constexpr (SEG == 2) {
+            if (be >= 0) {
+                unsigned long long* acc = reinterpret_cast<unsigned long long*>(bcast + 2);
+                stamp(2);
+                __builtin_amdgcn_s_setprio(0);
+                __syncthreads();                                    // (the candidates of the last tile are written: global stores complete)
+                if (tid == 0) {
+                    __hip_atomic_store(&args.unit_flag[unit], n_candidates + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    *acc = 0ULL;
+                }
+                lds_barrier();
+                unsigned long long part = 0;
+                for (uint32_t q = (uint32_t)tid; q < uidx; q += XRT_TILE) {
+                    const uint32_t* f = &args.unit_flag[(size_t)run * upr + q];
+                    uint32_t v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    while (v == 0u) {
+                        __builtin_amdgcn_s_sleep(8);
+                        v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
-                    if (mesh_pre) {
-                        // the records are rays that hit a face in the first pass: the rest of ShapeMesh.intersect and the
-                        // bounds here, on dense lanes; the Bragg uniforms go to those that are left, in ray order
-                        bool cand = false;
-                        if (have) {
-                            ray.o = X;
-                            const MeshHit h = mesh_rest(op.mesh, ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z, baux);
-                            X.x = h.x; X.y = h.y; X.z = h.z; baux = h.aux;
-                            cand = (h.hit != 0) && check_bounds<FULL>(op, X);
-                            if (HIST && !cand) {
-                                V3 xo = X, dd = ray.d;
-                                if (h.hit == 0) { xo.x = xo.y = xo.z = __builtin_nan(""); }
-                                if (local) {
-                                    xo = to_external(op.R, xo);
-                                    xo.x += op.origin[0]; xo.y += op.origin[1]; xo.z += op.origin[2];
-                                    dd = to_external(op.R, dd);
+                    part += (unsigned long long)(v - 1u);
+                }
+                if (part) atomicAdd(acc, part);
+                lds_barrier();
+                const unsigned long long before = uni64(*acc);
+                stamp(3);
+                if (args.dbg && tid == 0) args.dbg[(size_t)unit * 8 + 7] = ((unsigned long long)n_candidates << 32) | (before & 0xffffffffull);
+                // ---- second phase, wave by wave and without workgroup barriers (a barrier in front of every dependent step of
+                // a 256-candidate batch -- uniforms, test, survivor scan, drain -- left the vector units idle two thirds of the
+                // time).  Each of the four waves takes a quarter of the unit's candidates (a little less for the later ones, which
+                // first walk their copy of the stream head's ring over the quarters in front: raw generation, 192 words a step),
+                // 64 at a time, and keeps its own queue of reflected rays, which go through the elements behind the crystal 64 at
+                // a time.
+                if (n_candidates > 0u || last_unit) {
+                    const uint64_t words = 2ull * before + (args.base_words ? uni64(args.base_words[run]) : 0ull);
+                    const uint64_t chunk = words / (uint64_t)args.chunk_words;
+                    const uint64_t skip = words - chunk * (uint64_t)args.chunk_words;
+                    const KStream* ch = args.chunk_heads + (size_t)run * args.run_stride + chunk;
+                    const uint64_t c_next = uni64(ch->next), c_gen = uni64(ch->gen);
+                    const uint64_t first = c_next + skip;                          // the unit's first Bragg uniform (stream word)
+                    const int wave = tid >> 6, lane = tid & 63;
+                    // the workgroup's LDS in front of `small`, re-carved: four rings, four survivor queues
+                    uint32_t* wring = reinterpret_cast<uint32_t*>(lds_raw) + wave * XRT_RING;
+                    const uint32_t rec_bytes = 8u * (uint32_t)q_ncomp + (HIST ? 4u : 0u);
+                    const uint32_t pool = ((uint32_t)(reinterpret_cast<unsigned char*>(small) - lds_raw) - 4u * 4u * XRT_RING) / 4u & ~7u;
+                    uint32_t wq_cap = pool / rec_bytes;
+                    if (wq_cap > 128u) wq_cap = 128u;
+                    wq_cap &= ~1u;
+                    double* wq = reinterpret_cast<double*>(lds_raw + 4u * 4u * XRT_RING + (size_t)wave * pool);       // [q_ncomp][wq_cap]
+                    uint32_t* wqid = reinterpret_cast<uint32_t*>(wq + (size_t)q_ncomp * wq_cap);                         // [wq_cap] (HIST)
+                    // batches of 64 candidates [kb, ke) of this wave: 26 / 25.5 / 24.5 / 24 % of them
+                    const uint32_t n_batches = (n_candidates + 63u) >> 6;
+                    const uint32_t cut[5] = {0u, (n_batches * 133u + 256u) >> 9, (n_batches * 264u + 256u) >> 9, (n_batches * 389u + 256u) >> 9, n_batches};
+                    const uint32_t kb = cut[wave], ke = cut[wave + 1];
+                    uint64_t g64 = c_gen;       // words of the stream this wave's ring holds: [g64 - 1024, g64)
+                    auto ring_to = [&](uint64_t need) __attribute__((always_inline)) {      // whole steps of 192 words
+                        if (g64 < need) {
+                            const uint64_t steps = (need - g64 + 191ull) / 192ull;
+                            wave_walk_n(wring, (uint32_t)g64, 192ull * steps, lane);
+                            g64 += 192ull * steps;
+                        }
+                    };
+                    lds_barrier();              // (everyone is done with the first phase's rings and record buffer)
+                    // wave 0 walks the chunk head to the unit's first uniform, the others take copies and walk on to theirs
+                    if (wave == 0) {
+                        __builtin_amdgcn_s_setprio(3);
+                        for (int i = lane; i < (int)XRT_RING; i += 64) wring[i] = ch->ring[i];
+                        wave_fence();
+                        ring_to(first + 128ull);
+                        if (lane == 0) *acc = g64;
+                        __builtin_amdgcn_s_setprio(0);
+                    }
+                    lds_barrier();
+                    if (wave != 0) {
+                        const uint32_t* r0 = reinterpret_cast<const uint32_t*>(lds_raw);
+                        for (int i = lane; i < (int)XRT_RING; i += 64) wring[i] = r0[i];
+                        g64 = uni64(*acc);
+                        wave_fence();
+                    }
+                    lds_barrier();
+                    if (kb < ke) ring_to(first + 128ull * (uint64_t)(kb + 1u));
+                    uint32_t qn = 0;            // records in this wave's queue
+                    scl = scene_fresh(scene_g);
+                    const bool img_b = (SC.opt[be].flags & XRT_F_IMAGE) && args.images;
+                    // 64 (or the last qn) queued rays: the crystal's reflection where it was deferred, its pixel, the elements behind
+                    auto wave_drain = [&]() __attribute__((always_inline)) {
+                        const uint32_t n = qn < 64u ? qn : 64u;
+                        qn -= n;
+                        bool have_b = (uint32_t)lane < n;
+                        Ray rb;
+                        V3 Xb;
+                        uint32_t idb = 0;
+                        int auxb = 0;
+                        Xb.x = Xb.y = Xb.z = 0.0;
+                        rb.o = Xb; rb.d = Xb; rb.wl = wl_run;
+                        scl = scene_fresh(scene_g);
+                        if (have_b) {
+                            const double* r = wq + qn + lane;
+                            rb.o.x = r[0 * wq_cap]; rb.o.y = r[1 * wq_cap]; rb.o.z = r[2 * wq_cap];
+                            rb.d.x = r[3 * wq_cap]; rb.d.y = r[4 * wq_cap]; rb.d.z = r[5 * wq_cap];
+                            if (q_has_wl) rb.wl = r[6 * wq_cap];
+                            if (HIST) idb = wqid[qn + lane];
+                            const KOptic& opb = SC.opt[be];
+                            if constexpr (!EXT) {
+                                // InteractCrystal.interact -> reflect_vectors (optics/_InteractMirror.py:29-42), deferred from the test
+                                const V3 nrm = surface_normal<FULL>(opb, rb.o);
+                                const double dt = dot_e(rb.d, nrm);
+                                rb.d.x = rb.d.x - 2.0 * (dt * nrm.x);
+                                rb.d.y = rb.d.y - 2.0 * (dt * nrm.y);
+                                rb.d.z = rb.d.z - 2.0 * (dt * nrm.z);
+                                if (HIST) hist_write(args.hist, args.hmask, N, be + 1, idb, rb.o, rb.d, rb.wl, true);
+                            }
+                            if (img_b) pixel(opb, rb.o);
+                        }
+                        // elements behind the crystal (objects/_Dispatcher.py:166-196), the rays staying in their lanes
+                        for (int e = be + 1; e < SC.n_optics; e++) {
+                            scl = scene_fresh(scene_g);
+                            const KOptic& op = SC.opt[e];
+                            bool alive_b = false;
+                            if constexpr (EXT) {
+                                const bool local = (op.flags & XRT_F_TRACE_LOCAL) != 0;
+                                const bool is_mesh = (op.shape == XRT_SHAPE_MESH);
+                                if (have_b) {
+                                    if (local) {    // TraceObject.trace_global -> ray_to_local (optics/_TraceObject.py:146-148)
+                                        rb.o = to_local(op.R, sub3(rb.o, ld3(op.origin)));
+                                        rb.d = to_local(op.R, rb.d);
+                                    }
+                                    bool hit;
+                                    if (is_mesh) {
+                                        const MeshHit h = mesh_hit(op.mesh, rb.o.x, rb.o.y, rb.o.z, rb.d.x, rb.d.y, rb.d.z);
+                                        hit = h.hit != 0; Xb.x = h.x; Xb.y = h.y; Xb.z = h.z; auxb = h.aux;
+                                    } else hit = intersect_point<FULL>(op, rb, Xb, false, pre0);
+                                    alive_b = hit && check_bounds<FULL>(op, Xb);
+                                    if (HIST && !alive_b) {
+                                        V3 xo = Xb, dd = rb.d;
+                                        if (!hit) { xo.x = xo.y = xo.z = __builtin_nan(""); }
+                                        if (local) {
+                                            xo = to_external(op.R, xo);
+                                            xo.x += op.origin[0]; xo.y += op.origin[1]; xo.z += op.origin[2];
+                                            dd = to_external(op.R, dd);
+                                        }
+                                        hist_write(args.hist, args.hmask, N, e + 1, idb, xo, dd, rb.wl, false);
+                                    }
+                                    if (alive_b) {
+                                        rb.o = Xb;
+                                        if (op.interact != XRT_INTERACT_NONE) {
+                                            V3 nrm = is_mesh ? mesh_normal(op.mesh, Xb.x, Xb.y, auxb) : surface_normal<FULL>(op, Xb);
+                                            double dt = dot_e(rb.d, nrm);
+                                            rb.d.x = rb.d.x - 2.0 * (dt * nrm.x);
+                                            rb.d.y = rb.d.y - 2.0 * (dt * nrm.y);
+                                            rb.d.z = rb.d.z - 2.0 * (dt * nrm.z);
+                                        }
+                                        if (local) {    // ray_to_external (optics/_TraceObject.py:152-154)
+                                            rb.o = to_external(op.R, rb.o);
+                                            rb.o.x += op.origin[0]; rb.o.y += op.origin[1]; rb.o.z += op.origin[2];
+                                            rb.d = to_external(op.R, rb.d);
+                                        }
+                                        if (HIST) hist_write(args.hist, args.hmask, N, e + 1, idb, rb.o, rb.d, rb.wl, true);
+                                    }
                                 }
-                                hist_write(args.hist, args.hmask, N, be + 1, id, xo, dd, ray.wl, false);
+                            } else {
+                                if (have_b) {
+                                    bool hit = intersect_point<FULL>(op, rb, Xb, false, pre0);
+                                    alive_b = hit && check_bounds<FULL>(op, Xb);
+                                    if (HIST && !alive_b) {
+                                        V3 xo = Xb;
+                                        if (!hit) { xo.x = xo.y = xo.z = __builtin_nan(""); }
+                                        hist_write(args.hist, args.hmask, N, e + 1, idb, xo, rb.d, rb.wl, false);
+                                    }
+                                    // InteractObject / InteractMirror.reflect_vectors (optics/_InteractMirror.py:29-42)
+                                    if (alive_b) {
+                                        rb.o = Xb;
+                                        if (op.interact != XRT_INTERACT_NONE) {
+                                            V3 nrm = surface_normal<FULL>(op, Xb);
+                                            double dt = dot_e(rb.d, nrm);
+                                            rb.d.x = rb.d.x - 2.0 * (dt * nrm.x);
+                                            rb.d.y = rb.d.y - 2.0 * (dt * nrm.y);
+                                            rb.d.z = rb.d.z - 2.0 * (dt * nrm.z);
+                                        }
+                                        if (HIST) hist_write(args.hist, args.hmask, N, e + 1, idb, rb.o, rb.d, rb.wl, true);
+                                    }
+                                }
+                            }
+                            const unsigned long long ob = __ballot(alive_b);
+                            if (ob == 0ULL) break;
+                            if (lane == 0) atomicAdd(&cnt[e + 1], (unsigned long long)__popcll(ob));
+                            if (alive_b && (op.flags & XRT_F_IMAGE) && args.images) pixel(op, rb.o);
+                            have_b = alive_b;
+                        }
+                    };
+
+                    // ---- this wave's batches: candidates 64 k .. 64 k + 63, k = wave, wave + 4, ...
+                    V3 pf_x, pf_d;
+                    double pf_wl = wl_run;
+                    uint32_t pf_id = 0;
+                    int pf_aux = 0;
+                    pf_x.x = pf_x.y = pf_x.z = 0.0; pf_d = pf_x;
+                    if (kb < ke && 64u * kb + (uint32_t)lane < n_candidates)
+                        cand_load(ray_lo + (int64_t)(64u * kb + (uint32_t)lane), pf_x, pf_d, pf_wl, pf_id, pf_aux);
+                    for (uint32_t k = kb; k < ke; k++) {
+                        const uint32_t c = 64u * k + (uint32_t)lane;
+                        const bool have = c < n_candidates;
+                        bool alive = false;
+                        Ray ray;
+                        V3 X = pf_x;
+                        uint32_t id = pf_id;
+                        int baux = pf_aux;
+                        ray.o = X; ray.d = pf_d; ray.wl = pf_wl;
+#ifndef XRT_ABL_NOLOAD
+                        if (k + 1u < ke && c + 64u < n_candidates) cand_load(ray_lo + (int64_t)(c + 64u), pf_x, pf_d, pf_wl, pf_id, pf_aux);   // the wave's next batch
+#endif
+                        // this batch's uniforms: words first + 128 k .. + 128 (np.random.uniform(0,1,n_live), optics/_InteractCrystal.py:189)
+#ifndef XRT_ABL_NORING
+                        ring_to(first + 128ull * (uint64_t)(k + 1u));
+#endif
+                        scl = scene_fresh(scene_g);
+                        const KOptic& op = SC.opt[be];
+#ifdef XRT_ABL_NOTEST
+                        if (have && id == 0xffffffffu) {
+#else
+                        if (have) {
+#endif
+                            const uint32_t n = (uint32_t)first + 128u * k + 2u * (uint32_t)lane;
+                            const double test = 0.0 + (1.0 - 0.0) * mt_double(wring[n & XRT_RMASK], wring[(n + 1u) & XRT_RMASK]);
+                            if constexpr (EXT) {
+                                const bool local = (op.flags & XRT_F_TRACE_LOCAL) != 0;
+                                V3 nrm;
+                                if (op.shape == XRT_SHAPE_MESH) nrm = mesh_normal(op.mesh, X.x, X.y, baux);
+                                else nrm = surface_normal<FULL>(op, X);
+                                alive = bragg_accept(op, ray, nrm, test, wl_shared, bragg_shared);
+                                if (HIST && !alive) {
+                                    V3 xo = X, dd = ray.d;
+                                    if (local) {
+                                        xo = to_external(op.R, xo);
+                                        xo.x += op.origin[0]; xo.y += op.origin[1]; xo.z += op.origin[2];
+                                        dd = to_external(op.R, dd);
+                                    }
+                                    hist_write(args.hist, args.hmask, N, be + 1, id, xo, dd, ray.wl, false);
+                                }
+                                if (alive) {
+                                    ray.o = X;
+                                    double dt = dot_e(ray.d, nrm);
+                                    ray.d.x = ray.d.x - 2.0 * (dt * nrm.x);
+                                    ray.d.y = ray.d.y - 2.0 * (dt * nrm.y);
+                                    ray.d.z = ray.d.z - 2.0 * (dt * nrm.z);
+                                    if (local) {
+                                        ray.o = to_external(op.R, ray.o);
+                                        ray.o.x += op.origin[0]; ray.o.y += op.origin[1]; ray.o.z += op.origin[2];
+                                        ray.d = to_external(op.R, ray.d);
+                                    }
+                                    if (HIST) hist_write(args.hist, args.hmask, N, be + 1, id, ray.o, ray.d, ray.wl, true);
+                                }
+                            } else {
+                                // (the screen decides nearly every candidate from the incidence cosine alone; see bragg_batch)
+                                bool decided = false;
+                                V3 nu;
+                                if (test > 0.0 && ((op.scr_ok && wl_shared) || op.scr2_ok) && normal_direction(op, X, nu)) {
+                                    const double pp = (op.shape == XRT_SHAPE_PLANE ? 1.0 : dot_n(nu, nu)) * dot_n(ray.d, ray.d);
+                                    double y = __builtin_amdgcn_rsq(pp);
+                                    y = y * fma(-0.5 * pp * y, y, 1.5);
+                                    const double ca = fabs(dot_n(ray.d, nu)) * y;
+                                    alive = (op.scr_ok && wl_shared) ? bragg_screen(op, ca, test, decided)
+                                                                     : bragg_screen_wl(op, ca, ray.wl, test, decided);
+                                }
+                                if (!decided) alive = bragg_accept(op, ray, surface_normal<FULL>(op, X), test, wl_shared, bragg_shared);
+                                if (HIST && !alive) hist_write(args.hist, args.hmask, N, be + 1, id, X, ray.d, ray.wl, false);
+                                if (alive) ray.o = X;
                             }
                         }
-                        draw = wg_rank(cand, wave_tot, slot, tid, n_draws, rotw);
-                        have = cand;
-                    }
-                    if (have) {
-                        V3 nrm;
-                        if (op.shape == XRT_SHAPE_MESH) nrm = mesh_normal(op.mesh, X.x, X.y, baux);
-                        else nrm = surface_normal<FULL>(op, X);
-                        uint32_t n = spos + 2u * draw;
-                        double test = 0.0 + (1.0 - 0.0) * mt_double(stream[n & XRT_RMASK], stream[(n + 1u) & XRT_RMASK]);
-                        alive = bragg_accept(op, ray, nrm, test, wl_shared, bragg_shared);
-                        if (HIST && !alive) {
-                            V3 xo = X, dd = ray.d;
-                            if (local) {
-                                xo = to_external(op.R, xo);
-                                xo.x += op.origin[0]; xo.y += op.origin[1]; xo.z += op.origin[2];
-                                dd = to_external(op.R, dd);
-                            }
-                            hist_write(args.hist, args.hmask, N, be + 1, id, xo, dd, ray.wl, false);
-                        }
-                        if (alive) {
-                            ray.o = X;
-                            double dt = dot_e(ray.d, nrm);
-                            ray.d.x = ray.d.x - 2.0 * (dt * nrm.x);
-                            ray.d.y = ray.d.y - 2.0 * (dt * nrm.y);
-                            ray.d.z = ray.d.z - 2.0 * (dt * nrm.z);
-                            if (local) {
-                                ray.o = to_external(op.R, ray.o);
-                                ray.o.x += op.origin[0]; ray.o.y += op.origin[1]; ray.o.z += op.origin[2];
-                                ray.d = to_external(op.R, ray.d);
-                            }
-                            if (HIST) hist_write(args.hist, args.hmask, N, be + 1, id, ray.o, ray.d, ray.wl, true);
-                        }
-                    }
-                } else {
-                    // The reflection itself (exact normal: a square root and three divisions) waits until the
-                    // survivors are drained, on dense lanes; here the screen decides nearly every candidate from
-                    // the incidence cosine alone, |d . nu| / (|nu| |d|) with the un-normalised normal direction nu of a sphere.
-                    if (have) {
-                        q_load(q_wrap(qhead + vt), X, ray.d, ray.wl, id);
-                        uint32_t n = spos + 2u * vt;
-                        double test = 0.0 + (1.0 - 0.0) * mt_double(stream[n & XRT_RMASK], stream[(n + 1u) & XRT_RMASK]);
-                        bool decided = false;
-                        V3 nu;
-                        if (test > 0.0 && ((op.scr_ok && wl_shared) || op.scr2_ok) && normal_direction(op, X, nu)) {
-                            // (a plane's normal is the optic's z axis as the reference holds it -- |z| - 1 ~ 1e-9 for axes typed in
-                            //  with 8 digits -- and the reference does NOT divide by its length: neither does the screen)
-                            const double pp = (op.shape == XRT_SHAPE_PLANE ? 1.0 : dot_n(nu, nu)) * dot_n(ray.d, ray.d);
-                            double y = __builtin_amdgcn_rsq(pp);
-                            y = y * fma(-0.5 * pp * y, y, 1.5);
-                            const double ca = fabs(dot_n(ray.d, nu)) * y;
-                            alive = (op.scr_ok && wl_shared) ? bragg_screen(op, ca, test, decided)
-                                                             : bragg_screen_wl(op, ca, ray.wl, test, decided);
-                        }
-                        if (!decided) alive = bragg_accept(op, ray, surface_normal<FULL>(op, X), test, wl_shared, bragg_shared);
-#if XRT_ABLATE == 1
+#ifdef XRT_ABL_NOSURV
                         alive = alive && (id == 0xffffffffu);
 #endif
-                        if (HIST && !alive) hist_write(args.hist, args.hmask, N, be + 1, id, X, ray.d, ray.wl, false);
-                        if (alive) ray.o = X;
+                        // the reflected rays join the wave's queue
+                        const unsigned long long sb = __ballot(alive);
+                        if (sb != 0ULL) {
+                            const uint32_t n_new = (uint32_t)__popcll(sb);
+                            if (qn + n_new > wq_cap) wave_drain();
+                            if (alive) {
+                                const uint32_t at = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(sb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sb, 0u));
+                                double* r = wq + at;
+                                r[0 * wq_cap] = ray.o.x; r[1 * wq_cap] = ray.o.y; r[2 * wq_cap] = ray.o.z;
+                                r[3 * wq_cap] = ray.d.x; r[4 * wq_cap] = ray.d.y; r[5 * wq_cap] = ray.d.z;
+                                if (q_has_wl) r[6 * wq_cap] = ray.wl;
+                                if (HIST) wqid[at] = id;
+                            }
+                            if (lane == 0) atomicAdd(&cnt[be + 1], (unsigned long long)n_new);
+                            qn += n_new;
+                            wave_fence();
+                            while (qn >= 64u) wave_drain();
+                        }
+                    }
+                    while (qn > 0u) wave_drain();
+                    // ---- the run's last unit hands the stream on: position behind the run's last Bragg uniform, 512 words
+                    // generated ahead (the canonical form; a few more may be in the ring, which holds the 624 words in front all the same)
+                    if (last_unit) {
+                        const uint64_t end = first + 2ull * (uint64_t)n_candidates;
+                        if (wave == 0) ring_to(end + (uint64_t)XRT_AHEAD);
+                        lds_barrier();
+                        const uint32_t* r0 = reinterpret_cast<const uint32_t*>(lds_raw);
+                        for (int i = tid; i < (int)XRT_RING; i += XRT_TILE) st->ring[i] = r0[i];
+                        if (tid == 0) { st->next = end; st->gen = end + (uint64_t)XRT_AHEAD; }
                     }
                 }
-                spos += 2u * n_draws;
-                s_used += 2ull * n_draws;
-                const uint32_t head_old = qhead;
-                qhead = q_wrap(qhead + nb);
-                qcount -= nb;
-                // ---- the reflected rays join the survivor queue, which sits right below the candidates' head:
-                // [qhead - bcount, qhead).  The batch just freed [head_old, qhead); the new survivors go to its
-                // upper end by ordered rank, and the (< 64) survivors left from earlier batches are moved up
-                // behind them by a wave that has nothing else to do in this stage (virtual wave 3): it reads
-                // them in front of the scan's barrier and writes them behind it.
-                V3 mo, md;
-                double mwl = 0.0;
-                uint32_t mid = 0;
-                mo.x = mo.y = mo.z = 0.0; md = mo;
-                const bool mover = (vt >= 192u) && (vt - 192u < bcount);
-                if (mover) q_load(q_wrap(head_old + qcap - bcount + (vt - 192u)), mo, md, mwl, mid);
-                uint32_t n_s;
-                mt_step();
-                const uint32_t srank = wg_rank(alive, wave_tot, slot, tid, n_s, rotw);
-                if (tid == 0) cnt[be + 1] += n_s;
-                if (alive) q_store(q_wrap(qhead + qcap - n_s + srank), ray.o, ray.d, ray.wl, id);
-                if (mover && n_s < nb) q_store(q_wrap(qhead + qcap - n_s - bcount + (vt - 192u)), mo, md, mwl, mid);
-                bcount += n_s;
-                rotw = (rotw + ((nb + 63u) >> 6)) & 3u;
-                // ---- survivors: 64 at a time (everything that is left behind the run's last batch) through
-                // the elements behind the Bragg element, on one full wave
-                drain_survivors(last_tile && qcount == 0u);
+                stamp(4);
             }
-            if (be >= 0 && last_tile) drain_survivors(true);
         }
+
+        stamp(5);
+        if (SEG && args.dbg && tid == 0) args.dbg[(size_t)unit * 8 + 6] = cnt[be >= 0 ? be + 1 : 0];
 
         // ---- run done: counters out, stream head back to memory ---------------
         // canonical form: exactly 512 words generated ahead (what xrt_jump_kernel expects)
-        __syncthreads();
+        lds_barrier();
         if (counting) {
             if (tid == 0) args.unit_count[unit] = n_candidates;
-            __syncthreads();
+            lds_barrier();
             continue;
         }
-        if (!HIST) while ((sgen - spos) < XRT_AHEAD) { mt_step(); __syncthreads(); }
+        if (!HIST && last_unit) while ((sgen - spos) < XRT_AHEAD) { mt_step(); lds_barrier(); }
         lbins_flush();
         if (tid <= SC.n_optics && cnt[tid] != 0ULL) atomicAdd(&args.num_out[tid], cnt[tid]);
         // the stream head goes back to memory: always for a whole run; of a segmented run only the
@@ -1769,12 +2242,12 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
             // run's new head (of a segmented run: chunk head 0, by the last segment), brought to the canonical form
             // -- 512 words generated ahead, what the next iteration's jump expects -- in the ring of a source head
             // that is done
-            if (!SEG || seg + 1u == (uint32_t)args.n_seg) {
+            if (last_unit) {
                 uint32_t* sr = rings;
-                __syncthreads();
+                lds_barrier();
                 for (int i = tid; i < (int)XRT_RING; i += XRT_TILE) sr[i] = st_in->ring[i];
                 uint32_t g = (uint32_t)s_gen0;
-                __syncthreads();
+                lds_barrier();
                 while ((g - spos) < XRT_AHEAD) {
                     uint32_t chunk = XRT_AHEAD - (g - spos);
                     if (chunk > 227u) chunk = 227u;
@@ -1783,20 +2256,20 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
                         sr[n & XRT_RMASK] = mt_mix(sr[(n - 624u) & XRT_RMASK], sr[(n - 623u) & XRT_RMASK], sr[(n - 227u) & XRT_RMASK]);
                     }
                     g += chunk;
-                    __syncthreads();
+                    lds_barrier();
                 }
                 for (int i = tid; i < (int)XRT_RING; i += XRT_TILE) st->ring[i] = sr[i];
                 if (tid == 0) { st->next = s_next0; st->gen = s_gen0 + (uint64_t)(uint32_t)(g - (uint32_t)s_gen0); }
             }
         } else
-        if (!SEG || seg + 1u == (uint32_t)args.n_seg) {
+        if (last_unit && !deferred) {
             for (int i = tid; i < (int)XRT_RING; i += XRT_TILE) st->ring[i] = stream[i];
             if (tid == 0) {
                 st->next = s_next0 + s_used;
-                st->gen = s_gen0 + (uint64_t)(uint32_t)(sgen - (uint32_t)s_gen0);
+                st->gen = s_next0 + s_used + (uint64_t)(sgen - spos);
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 
@@ -2084,38 +2557,70 @@ static size_t staged_bytes(const xrt_scene_t* sc, int n_runs)
     return al256((size_t)staged_slots(sc, n_runs) * staged_slot_bytes(sc) + 256);
 }
 
-// Few runs of many rays: split every run into segments so that the whole chip has work
-// (the unit of parallelism is otherwise one workgroup per run).  seg_len is a multiple of the tile.
+// Few runs of many rays: split every run into work units so that the whole chip has work (the unit of parallelism is
+// otherwise one workgroup per run).  A run is cut into n_seg segments, each with its own jump-positioned source heads
+// (a jump costs about as much as tracing 15 000 rays), and a segment into n_sub parts that share those heads: part j
+// first walks them over the rays in front of its own (raw generation only, ~20 x faster than tracing them).  The
+// stream behind the source arrays gets chunk heads, chunk_words apart; a unit's first Bragg uniform lies at most that
+// far behind one of them.  Lengths are multiples of the tile.
 struct SegPlan {
     int n_seg; int64_t seg_len;     // n_seg == 1 && seg_len == 0: one unit per run, unsegmented kernels
-    int n_chunk_heads;              // stream heads behind the source arrays, 2 * seg_len words apart
+    int n_sub; int64_t sub_len;     // seg_len = n_sub * sub_len
+    int n_chunk_heads; int64_t chunk_words;
     int n_gchunks; int64_t gpairs;  // Gaussian wavelengths: chunks of the candidate stream, candidate pairs per chunk
 };
+static int count_heads(const xrt_scene_t* sc);
+static bool needs_ext(const xrt_scene_t* sc);
+static int bragg_element(const xrt_scene_t* sc)
+{
+    int be = -1;
+    for (int e = 0; e < sc->n_optics; e++)
+        if (sc->optics[e].interact == XRT_INTERACT_CRYSTAL && (sc->optics[e].flags & XRT_F_CHECK_BRAGG)) be = e;
+    return be;
+}
+// cost model of the plan, in microseconds of the whole chip (measured on MI355X)
+#define XRT_COST_JUMP_US  0.30      // one jump job
+#define XRT_COST_SKIP_US  0.54      // one workgroup walking its heads over one tile of rays / 512 stream words (latency)
 static SegPlan plan_segments(const xrt_scene_t* sc, int n_runs)
 {
-    SegPlan p = {1, 0, 0, 0, 0};
+    SegPlan p = {1, 0, 1, 0, 0, 0, 0, 0};
     if (needs_staged(sc)) return p;
     const int64_t N = sc->source.intensity;
     const bool gauss = gauss_prepared(sc->source);
-    int want = 0;
-    int64_t min_len = 4096;                     // below this the jump-ahead of a unit's heads outweighs its rays
-    if (const char* e = getenv("XICSRT_SEGMENTS")) { want = atoi(e); min_len = XRT_TILE; }
+    int want = 0, want_sub = 0;                 // units per run, parts per segment (0: by the cost model)
+    int64_t min_len = 4096;                     // below this the set-up of a unit outweighs its rays
+    if (const char* e = getenv("XICSRT_SEGMENTS")) { want = atoi(e); want_sub = 1; min_len = XRT_TILE; }
     else if (n_runs < 256) {
-        int target = 512;                       // about two units per CU
+        // one round of units, all resident together and of one size: as many as workgroups fit on the chip (a second
+        // round for a few units more would double the time), four per CU (two for the mesh / local-frame variant)
+        int target = 256 * (needs_ext(sc) ? 2 : 4);
         if (const char* t = getenv("XICSRT_TARGET_UNITS")) target = atoi(t) > 0 ? atoi(t) : target;
-        want = (target + n_runs - 1) / n_runs;
+        want = target / n_runs;
     }
-    int64_t n = 1, len = 0;
+    if (const char* e = getenv("XICSRT_SUBUNITS")) want_sub = atoi(e) > 0 ? atoi(e) : want_sub;
+    int64_t n = 1, len = 0, sub = 1, sublen = 0;
     if (!(want <= 1 || N < 2 * XRT_TILE || getenv("XICSRT_NO_JUMP"))) {
-        len = (N + want - 1) / want;
-        if (len < min_len) len = min_len;
-        len = (len + XRT_TILE - 1) / XRT_TILE * XRT_TILE;
+        sublen = (N + want - 1) / want;
+        if (sublen < min_len) sublen = min_len;
+        sublen = (sublen + XRT_TILE - 1) / XRT_TILE * XRT_TILE;
+        const int64_t units = (N + sublen - 1) / sublen;
+        if (want_sub > 0) sub = want_sub;
+        else {
+            // segments: jump jobs (n_heads per segment and run) against the walk of a segment's last part
+            const double nh = (double)(count_heads(sc) > 0 ? count_heads(sc) : 1);
+            const double s_opt = sqrt(((double)N / XRT_TILE) * XRT_COST_SKIP_US / (nh * (double)n_runs * XRT_COST_JUMP_US));
+            sub = (int64_t)floor((double)units / (s_opt > 1.0 ? s_opt : 1.0) + 0.5);
+        }
+        if (sub > 16) sub = 16;
+        if (sub > units) sub = units;
+        if (sub < 1) sub = 1;
+        len = sub * sublen;
         n = (N + len - 1) / len;
-        if (n <= 1 || n > 4096) { n = 1; len = 0; }
+        if (n * sub <= 1 || n > 4096) { n = 1; len = 0; sub = 1; sublen = 0; }
     }
-    if (n == 1 && !gauss) return p;
-    if (n == 1) len = (N + XRT_TILE - 1) / XRT_TILE * XRT_TILE;       // whole runs through the SEG kernels
-    p.n_seg = (int)n; p.seg_len = len;
+    if (n == 1 && sub == 1 && !gauss) return p;
+    if (n == 1 && sub == 1) { len = (N + XRT_TILE - 1) / XRT_TILE * XRT_TILE; sublen = len; }      // whole runs through the SEG kernels
+    p.n_seg = (int)n; p.seg_len = len; p.n_sub = (int)sub; p.sub_len = sublen;
     uint64_t gauss_words = 0;
     if (gauss) {
         // candidate pairs that certainly yield N/2 accepted ones (acceptance pi/4; mean + ~8 sigma + slack)
@@ -2131,36 +2636,117 @@ static SegPlan plan_segments(const xrt_scene_t* sc, int n_runs)
         p.n_gchunks = (int)((cand + per - 1) / per);
         gauss_words = 4ull * (uint64_t)p.gpairs * (uint64_t)p.n_gchunks;
     }
-    const uint64_t CH = 2ull * (uint64_t)len;
-    p.n_chunk_heads = (int)((gauss_words + 2ull * (uint64_t)N + CH - 1) / CH) + 1;
+    // chunk heads over the words behind the source arrays that Bragg draws can start at: [0, gauss_words + 2 N]
+    const uint64_t W = gauss_words + 2ull * (uint64_t)N;
+    if (bragg_element(sc) < 0) {
+        // no Bragg draws: only the run's last unit opens the stream, to hand it on (behind the Gaussian words)
+        p.n_chunk_heads = 1; p.chunk_words = (int64_t)(W + 2);
+    } else {
+        double nc = sqrt(((double)W / 512.0) * XRT_COST_SKIP_US / ((double)n_runs * XRT_COST_JUMP_US));
+        if (const char* e = getenv("XICSRT_CHUNK_HEADS")) nc = atof(e);
+        if (nc < 1.0) nc = 1.0;
+        if (nc > 2048.0) nc = 2048.0;
+        uint64_t CH = (uint64_t)((double)W / nc) + 1;
+        CH = (CH + 1023) / 1024 * 1024;
+        p.chunk_words = (int64_t)CH;
+        p.n_chunk_heads = (int)(W / CH) + 1;
+    }
     return p;
 }
-static bool seg_active(const SegPlan& p) { return p.n_seg > 1 || p.n_gchunks > 0; }
+static bool seg_active(const SegPlan& p) { return p.n_seg > 1 || p.n_sub > 1 || p.n_gchunks > 0; }
 // jobs of a run: [segment][source head], the chunk heads, the chunk heads of the Gaussian candidate stream
 static int seg_jobs(const xrt_scene_t* sc, const SegPlan& p) { return p.n_seg * count_heads(sc) + p.n_chunk_heads + p.n_gchunks; }
-// segmented runs: [dst heads n_runs x n_jobs][polys][offsets][unit counts][gauss: values, chunk counts, words]
+// segmented runs: [dst heads n_runs x n_jobs][polys][offsets][unit counts / flags][gauss: values, chunk counts, words]
 static size_t seg_bytes(const xrt_scene_t* sc, int n_runs)
 {
     const SegPlan p = plan_segments(sc, n_runs);
     if (!seg_active(p)) return 0;
     const size_t nj = (size_t)seg_jobs(sc, p);
     size_t b = al256(sizeof(KStream) * nj * (size_t)n_runs) + al256(sizeof(uint32_t) * 624 * nj) + al256(sizeof(uint64_t) * nj)
-               + al256(sizeof(uint32_t) * (size_t)n_runs * (size_t)p.n_seg) + 256;
+               + al256(sizeof(uint32_t) * (size_t)n_runs * (size_t)p.n_seg * (size_t)p.n_sub) + 256;
     if (p.n_gchunks > 0)
         b += al256(sizeof(double) * (size_t)n_runs * (size_t)sc->source.intensity) + al256(sizeof(uint32_t) * (size_t)n_runs * (size_t)p.n_gchunks)
              + al256(sizeof(uint64_t) * (size_t)n_runs);
     return b;
+}
+// One-pass segmented runs park every unit's Bragg candidates in HBM: per run and ray of capacity 7 doubles, the ray
+// index and the hit face (64 B).  At the end of the workspace; beyond the budget the two-pass route is taken.
+#define XRT_CAND_BUDGET      (48ull << 30)
+#define XRT_CAND_BUDGET_TAIL (8ull << 30)       // for the < 256 runs an unsegmented launch leaves to a second pass
+static size_t cand_capacity(const xrt_scene_t* sc) { return ((size_t)(sc->source.intensity > 0 ? sc->source.intensity : 1) + 255) & ~(size_t)255; }
+static size_t cand_bytes(const xrt_scene_t* sc, int n_runs, size_t budget)
+{
+    const SegPlan p = plan_segments(sc, n_runs);
+    if (!seg_active(p) || p.n_seg * p.n_sub <= 1 || bragg_element(sc) < 0 || env_on("XICSRT_SEG_TWO_PASS")) return 0;
+    const size_t b = al256((size_t)n_runs * cand_capacity(sc) * 64) + 256;
+    return b <= budget ? b : 0;
 }
 
 static size_t ws_off_plasma_rays(const xrt_scene_t* sc, int n_runs)
 {
     return al256(ws_off_staged(sc, n_runs) + staged_bytes(sc, n_runs) + meshes_bytes(sc) + plasma_bytes(sc) + seg_bytes(sc, n_runs) + 256);
 }
+// Replicas of the pixel bins for the fused kernel (see KArgs.image_rep): as many as fit 64 MiB, at most 32; behind
+// the plasma arrays.  One replica = none (the kernel adds into the caller's bins).
+static int image_replicas(const xrt_scene_t* sc)
+{
+    if (sc->image_bins <= 0) return 1;
+    int r = 16;
+    if (const char* e = getenv("XICSRT_IMAGE_REPLICAS")) { const int v = atoi(e); if (v >= 1 && v <= 64) r = v; }
+    while (r > 1 && (size_t)r * (size_t)sc->image_bins * 8 > (64ull << 20)) r >>= 1;
+    return r;
+}
+static size_t image_rep_bytes(const xrt_scene_t* sc)
+{
+    const int r = image_replicas(sc);
+    return r > 1 ? al256((size_t)r * (size_t)sc->image_bins * 8) + 256 : 0;
+}
+static size_t ws_off_image_rep(const xrt_scene_t* sc, int n_runs) { return al256(ws_off_plasma_rays(sc, n_runs) + plasma_ws_bytes(sc, n_runs) + 256); }
+// everything but the candidate arrays of the one-pass segmented route (they come last)
+static size_t ws_base_bytes(const xrt_scene_t* sc, int n_runs) { return ws_off_image_rep(sc, n_runs) + image_rep_bytes(sc) + 256; }
+
+__global__ void xrt_image_reduce_kernel(unsigned long long* rep, int n_rep, uint64_t bins, unsigned long long* out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= bins) return;
+    unsigned long long s = 0;
+    for (int r = 0; r < n_rep; r++) { s += rep[(size_t)r * bins + i]; rep[(size_t)r * bins + i] = 0ULL; }
+    if (s) out[i] += s;
+}
+// the fused kernels of the calls in between add into the replicas (zeroed once per xrt_trace / xrt_trace_history)
+static int image_rep_begin(const xrt_scene_t* sc, char* ws, int n_runs, KArgs* a, hipStream_t stream)
+{
+    a->image_rep = 1; a->image_stride = 0;
+    const int r = image_replicas(sc);
+    if (!a->images || r <= 1) return 0;
+    unsigned long long* rep = reinterpret_cast<unsigned long long*>(ws + ws_off_image_rep(sc, n_runs));
+    HIP_TRY(hipMemsetAsync(rep, 0, (size_t)r * (size_t)sc->image_bins * 8, stream));
+    a->image_rep = (uint32_t)r; a->image_stride = (uint64_t)sc->image_bins; a->images_rep = rep;
+    return 0;
+}
+static int image_rep_end(const xrt_scene_t* sc, char* ws, int n_runs, const KArgs& a, unsigned long long* out, hipStream_t stream)
+{
+    if (a.image_rep <= 1 || !out) return 0;
+    unsigned long long* rep = reinterpret_cast<unsigned long long*>(ws + ws_off_image_rep(sc, n_runs));
+    hipLaunchKernelGGL(xrt_image_reduce_kernel, dim3((unsigned)((sc->image_bins + 255) / 256)), dim3(256), 0, stream,
+                       rep, (int)a.image_rep, (uint64_t)sc->image_bins, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+static bool tail_split_possible(const xrt_scene_t* sc);
 extern "C" size_t xrt_workspace_bytes(const xrt_scene_t* sc, int32_t n_runs)
 {
     if (!sc || n_runs < 0) return 0;
     if (n_runs < 1) n_runs = 1;
-    return ws_off_plasma_rays(sc, n_runs) + plasma_ws_bytes(sc, n_runs) + 256;
+    size_t need = ws_base_bytes(sc, n_runs) + cand_bytes(sc, n_runs, XRT_CAND_BUDGET);
+    // xrt_trace may leave the last < 256 runs of an unsegmented launch to a second pass over the same workspace,
+    // which takes the segmented route with a layout of its own: the workspace holds that as well
+    if (n_runs > 256 && tail_split_possible(sc))
+        for (int t = 1; t < 256; t++) {
+            const size_t b = ws_base_bytes(sc, t) + cand_bytes(sc, t, XRT_CAND_BUDGET_TAIL);
+            if (b > need) need = b;
+        }
+    return need;
 }
 static size_t ws_off_seg(const xrt_scene_t* sc, int n_runs)
 {
@@ -2587,13 +3173,18 @@ static const KScene* device_scene(char* ws) { return reinterpret_cast<const KSce
 // xrt_trace lets the unsegmented launch leave out such a tail (< 256 runs) and traces it as a call of its own, which
 // takes the segmented route.  t_tail: -1 not allowed here, 0 allowed (set to the number of runs left out), > 0 decided.
 static thread_local int t_tail = -1;
+static bool tail_split_possible(const xrt_scene_t* sc)
+{
+    return sc->source.intensity >= 200000 && !needs_staged(sc) && !env_on("XICSRT_NO_TAIL_SPLIT");
+}
 
-template <bool HIST, int VARIANT, bool SEG = false>
+template <bool HIST, int VARIANT, int SEG = 0>
 static int launch_variant(const KScene* ks, const KArgs& a_in, int n_runs, size_t lds, hipStream_t stream, bool may_leave_tail = false)
 {
     KArgs a = a_in;
+    if (a.image_rep > 1u && a.images) a.images = a.images_rep;      // (the staged kernels add into the caller's bins)
 #ifdef XRT_DEV_ONLY_LEAN     // development builds: only the lean kernel is compiled (seconds instead of a minute)
-    if constexpr (HIST || VARIANT != 0 || SEG) return fail(-3, "%s", "development build: lean kernel only");
+    if constexpr (HIST || VARIANT != 0) return fail(-3, "%s", "development build: lean kernels only");
     else {
 #endif
     auto kern = xrt_trace_kernel<HIST, VARIANT, SEG>;
@@ -2617,7 +3208,7 @@ static int launch_variant(const KScene* ks, const KArgs& a_in, int n_runs, size_
         if (t_tail == 0 && n_runs > grid && (n_runs % grid) < 256) t_tail = n_runs % grid;
         if (t_tail > 0) { n_runs -= t_tail; a.n_runs = n_runs; }
     }
-    const int units = SEG ? n_runs * a.n_seg : n_runs;
+    const int units = SEG ? n_runs * a.n_seg * a.n_sub : n_runs;
     if (grid > units) grid = units;
     if (grid < 1) grid = 1;
     int ti = -1;
@@ -2640,7 +3231,7 @@ static int launch_variant(const KScene* ks, const KArgs& a_in, int n_runs, size_
 // canonical form and the arrays are long enough, else the sequential walk), then propagate
 // `ahead`: words every stream head has generated beyond `next` when this is called (XRT_AHEAD: the
 // canonical form between kernels; 624: an imported state after xrt_advance_kernel; 0: unknown)
-static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArgs a, int n_runs, bool hist,
+static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size_t ws_bytes, KArgs a, int n_runs, bool hist,
                          int ahead, hipStream_t stream, bool force_staged = false)
 {
     const bool canonical = ahead == (int)XRT_AHEAD;
@@ -2768,23 +3359,24 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
     if (seg_active(plan)) {
         // ---- segmented runs -------------------------------------------------------------------------
         g_paths |= XRT_PATH_FUSED | XRT_PATH_SEGMENTED | XRT_PATH_JUMP;
-        const int S = plan.n_seg, nj = seg_jobs(sc, plan);
-        const int64_t L = plan.seg_len, CH = 2 * L;
-        int be = -1;
-        for (int e = 0; e < sc->n_optics; e++)
-            if (sc->optics[e].interact == XRT_INTERACT_CRYSTAL && (sc->optics[e].flags & XRT_F_CHECK_BRAGG)) be = e;
+        const int S = plan.n_seg, M = plan.n_sub, nj = seg_jobs(sc, plan);
+        if (env_on("XICSRT_PLAN_DEBUG"))
+            fprintf(stderr, "[xicsrt] plan: runs %d, %d segments x %d parts of %lld rays, %d chunk heads every %lld words, %d jump jobs per run\n",
+                    n_runs, S, M, (long long)plan.sub_len, plan.n_chunk_heads, (long long)plan.chunk_words, nj);
+        const int64_t L = plan.seg_len, CH = plan.chunk_words;
+        const int be = bragg_element(sc);
         char* base = ws + ws_off_seg(sc, n_runs);
         KStream* dst = reinterpret_cast<KStream*>(base);
         uint32_t* d_polys = reinterpret_cast<uint32_t*>(base + al256(sizeof(KStream) * (size_t)nj * (size_t)n_runs));
         uint64_t* d_off = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(d_polys) + al256(sizeof(uint32_t) * 624 * (size_t)nj));
         uint32_t* d_cnt = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(d_off) + al256(sizeof(uint64_t) * (size_t)nj));
-        double* d_wl = reinterpret_cast<double*>(reinterpret_cast<char*>(d_cnt) + al256(sizeof(uint32_t) * (size_t)n_runs * (size_t)S) + 256);
+        double* d_wl = reinterpret_cast<double*>(reinterpret_cast<char*>(d_cnt) + al256(sizeof(uint32_t) * (size_t)n_runs * (size_t)S * (size_t)M) + 256);
         uint32_t* d_gacc = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(d_wl) + al256(sizeof(double) * (size_t)n_runs * (size_t)N));
         uint64_t* d_gend = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(d_gacc) + al256(sizeof(uint32_t) * (size_t)n_runs * (size_t)(plan.n_gchunks > 0 ? plan.n_gchunks : 1)));
         const int n_ch = plan.n_chunk_heads, n_gch = plan.n_gchunks;
         const uint64_t GCH = 4ull * (uint64_t)plan.gpairs;
         // polynomials + offsets of a plan live in pinned host memory and are reused by later calls
-        struct PlanCache { int64_t N, L, gpairs; int S, nj, n_ch; uint32_t used; int n_arrays, ahead; uint32_t* polys; uint64_t* offs; };
+        struct PlanCache { int64_t N, L, gpairs, CH; int S, nj, n_ch; uint32_t used; int n_arrays, ahead; uint32_t* polys; uint64_t* offs; };
         static std::mutex plan_mu;
         static std::vector<PlanCache> plans;
         PlanCache hit;
@@ -2793,7 +3385,7 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
             std::lock_guard<std::mutex> lock(plan_mu);
             for (const PlanCache& c : plans)
                 if (c.N == N && c.L == L && c.S == S && c.nj == nj && c.used == ks.src.array_used && c.n_arrays == ks.src.n_arrays &&
-                    c.ahead == ahead && c.n_ch == n_ch && c.gpairs == plan.gpairs) hit = c;
+                    c.ahead == ahead && c.n_ch == n_ch && c.gpairs == plan.gpairs && c.CH == CH) hit = c;
         }
         if (hit.polys) {
             HIP_TRY(hipMemcpyAsync(d_polys, hit.polys, sizeof(uint32_t) * 624 * (size_t)nj, hipMemcpyHostToDevice, stream));
@@ -2822,7 +3414,7 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
         }
         PlanCache c;
         c.N = N; c.L = L; c.S = S; c.nj = nj; c.used = ks.src.array_used; c.n_arrays = ks.src.n_arrays; c.ahead = ahead;
-        c.n_ch = n_ch; c.gpairs = plan.gpairs;
+        c.n_ch = n_ch; c.gpairs = plan.gpairs; c.CH = CH;
         c.polys = nullptr; c.offs = nullptr;
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c.polys), sizeof(uint32_t) * 624 * (size_t)nj, hipHostMallocDefault));
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c.offs), sizeof(uint64_t) * (size_t)nj, hipHostMallocDefault));
@@ -2855,6 +3447,24 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
         a.progress = env_on("XICSRT_NO_PRIORITY_FEEDBACK") ? nullptr : reinterpret_cast<unsigned long long*>(ws + 32);
         a.n_seg = S; a.seg_len = L; a.unit_count = d_cnt; a.chunk_heads = dst + (size_t)S * nh; a.chunk_words = CH;
         a.run_stride = nj;
+        a.n_sub = M; a.sub_len = plan.sub_len;
+        // one pass (candidates parked in HBM behind everything else) when the workspace holds them
+        const size_t cand_need = cand_bytes(sc, n_runs, XRT_CAND_BUDGET);
+        const bool one_pass = be >= 0 && S * M > 1 && cand_need > 0 && ws_base_bytes(sc, n_runs) + cand_need <= ws_bytes;
+        if (one_pass) {
+            const size_t cap = cand_capacity(sc);
+            char* cb = ws + ws_base_bytes(sc, n_runs);
+            a.cand = reinterpret_cast<double*>(cb);
+            a.cand_id = reinterpret_cast<uint32_t*>(cb + (size_t)n_runs * cap * 56);
+            a.cand_aux = a.cand_id + (size_t)n_runs * cap;
+            a.cand_cap = (int64_t)cap;
+            a.unit_flag = d_cnt;
+            HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(uint32_t) * (size_t)n_runs * (size_t)S * (size_t)M, stream));
+            g_paths |= XRT_PATH_ONE_PASS;
+        }
+        a.dbg = nullptr;
+        if (const char* e = getenv("XICSRT_UNIT_CLOCKS")) a.dbg = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0));   // development: device buffer [units][8]
+
         a.wl_array = nullptr; a.base_words = nullptr;
         if (n_gch > 0) {
             g_paths |= XRT_PATH_GAUSS_PREPARED;
@@ -2879,20 +3489,23 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, KArg
         if (variant == 0 && lds_bins_wanted(sc, a.images != nullptr, hist)) variant = 4;
         const size_t lds = plan_queue(ks, nh, variant == 2, hist, &a, variant == 4 ? (uint32_t)((sc->image_bins + 1) / 2) : 0u);
         if (variant == 4) g_paths |= XRT_PATH_LDS_BINS;
-        // (a run that is one segment has nothing in front of it: no count pass)
-        for (int mode = ((be >= 0 && S > 1) ? 1 : 2); mode <= 2; mode++) {
+        // (a run that is one unit has nothing in front of it: no count pass)
+        for (int mode = ((be >= 0 && S * M > 1 && !one_pass) ? 1 : 2); mode <= 2; mode++) {
             a.mode = mode;
             HIP_TRY(hipMemsetAsync(ws, 0, 64, stream));
             int st;
-            if (variant == 4) st = launch_variant<false, 4, true>(device_scene(ws), a, n_runs, lds, stream);
-            else if (hist) st = variant == 3 ? launch_variant<true, 3, true>(device_scene(ws), a, n_runs, lds, stream)
-                         : variant == 2 ? launch_variant<true, 2, true>(device_scene(ws), a, n_runs, lds, stream)
-                         : variant == 1 ? launch_variant<true, 1, true>(device_scene(ws), a, n_runs, lds, stream)
-                                        : launch_variant<true, 0, true>(device_scene(ws), a, n_runs, lds, stream);
-            else      st = variant == 3 ? launch_variant<false, 3, true>(device_scene(ws), a, n_runs, lds, stream)
-                         : variant == 2 ? launch_variant<false, 2, true>(device_scene(ws), a, n_runs, lds, stream)
-                         : variant == 1 ? launch_variant<false, 1, true>(device_scene(ws), a, n_runs, lds, stream)
-                                        : launch_variant<false, 0, true>(device_scene(ws), a, n_runs, lds, stream);
+#define XRT_LAUNCH_SEG(SEGV)                                                                                                     \
+            if (variant == 4) st = launch_variant<false, 4, SEGV>(device_scene(ws), a, n_runs, lds, stream);                     \
+            else if (hist) st = variant == 3 ? launch_variant<true, 3, SEGV>(device_scene(ws), a, n_runs, lds, stream)           \
+                         : variant == 2 ? launch_variant<true, 2, SEGV>(device_scene(ws), a, n_runs, lds, stream)                \
+                         : variant == 1 ? launch_variant<true, 1, SEGV>(device_scene(ws), a, n_runs, lds, stream)                \
+                                        : launch_variant<true, 0, SEGV>(device_scene(ws), a, n_runs, lds, stream);               \
+            else      st = variant == 3 ? launch_variant<false, 3, SEGV>(device_scene(ws), a, n_runs, lds, stream)               \
+                         : variant == 2 ? launch_variant<false, 2, SEGV>(device_scene(ws), a, n_runs, lds, stream)               \
+                         : variant == 1 ? launch_variant<false, 1, SEGV>(device_scene(ws), a, n_runs, lds, stream)               \
+                                        : launch_variant<false, 0, SEGV>(device_scene(ws), a, n_runs, lds, stream);
+            if (one_pass) { XRT_LAUNCH_SEG(2) } else { XRT_LAUNCH_SEG(1) }
+#undef XRT_LAUNCH_SEG
             if (st) return st;
         }
         return 0;
@@ -2956,7 +3569,7 @@ extern "C" int xrt_mt_jump_poly(uint64_t J, uint32_t* out624)
 }
 
 static int trace_runs(const xrt_scene_t* sc, const uint32_t* seeds, int32_t n_runs, int32_t n_iter,
-                      uint64_t* num_out, uint64_t* images, void* workspace, void* stream_, bool clear_status)
+                      uint64_t* num_out, uint64_t* images, void* workspace, size_t ws_bytes, void* stream_, bool clear_status)
 {
     int st = 0;
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
@@ -2982,13 +3595,15 @@ static int trace_runs(const xrt_scene_t* sc, const uint32_t* seeds, int32_t n_ru
     memset(&a, 0, sizeof(a));
     a.num_out = reinterpret_cast<unsigned long long*>(num_out);
     a.images = reinterpret_cast<unsigned long long*>(images);
+    st = image_rep_begin(sc, ws, n_runs, &a, stream);
+    if (st) return st;
     // iterations share each run's stream (xicsrt_raytrace.py:153): the stream head left by
     // iteration i is where iteration i+1 starts
     for (int it = 0; it < n_iter; it++) {
-        st = run_iteration(sc, ks, ws, a, n_runs, false, (int)XRT_AHEAD, stream);
+        st = run_iteration(sc, ks, ws, ws_bytes, a, n_runs, false, (int)XRT_AHEAD, stream);
         if (st) return st;
     }
-    return 0;
+    return image_rep_end(sc, ws, n_runs, a, a.images, stream);
 }
 
 extern "C" int xrt_trace(const xrt_scene_t* sc, const uint32_t* seeds, int32_t n_runs, int32_t n_iter,
@@ -3001,12 +3616,14 @@ extern "C" int xrt_trace(const xrt_scene_t* sc, const uint32_t* seeds, int32_t n
     if (workspace_bytes < xrt_workspace_bytes(sc, n_runs)) return fail(-4, "%s", "workspace too small");
     // (see t_tail: the unsegmented launch may leave the last < 256 runs to a second pass over the same workspace)
     // (a second pass costs about a millisecond of set-up: only where a run takes longer than that)
-    t_tail = sc->source.intensity >= 200000 ? 0 : -1;
-    st = trace_runs(sc, seeds, n_runs, n_iter, num_out, images, workspace, stream_, true);
+    t_tail = tail_split_possible(sc) ? 0 : -1;
+    st = trace_runs(sc, seeds, n_runs, n_iter, num_out, images, workspace, workspace_bytes, stream_, true);
     const int tail = t_tail;
     t_tail = -1;
     if (st || tail <= 0) return st;
-    return trace_runs(sc, seeds + (n_runs - tail), tail, n_iter, num_out, images, workspace, stream_, false);
+    // (the tail's layout is part of xrt_workspace_bytes(sc, n_runs); checked all the same)
+    if (workspace_bytes < ws_base_bytes(sc, tail)) return fail(-4, "%s", "workspace too small for the second pass over the last runs");
+    return trace_runs(sc, seeds + (n_runs - tail), tail, n_iter, num_out, images, workspace, workspace_bytes, stream_, false);
 }
 
 extern "C" int xrt_trace_history(const xrt_scene_t* sc, const xrt_rng_state_t* state_in,
@@ -3052,7 +3669,11 @@ extern "C" int xrt_trace_history(const xrt_scene_t* sc, const xrt_rng_state_t* s
         HIP_TRY(hipGetLastError());
         ahead = 624;
     }
-    st = run_iteration(sc, ks, ws, a, 1, true, ahead, stream, force_staged);
+    st = image_rep_begin(sc, ws, 1, &a, stream);
+    if (st) return st;
+    st = run_iteration(sc, ks, ws, workspace_bytes, a, 1, true, ahead, stream, force_staged);
+    if (st) return st;
+    st = image_rep_end(sc, ws, 1, a, a.images, stream);
     if (st) return st;
     if (state_out) {
         hipLaunchKernelGGL(xrt_export_state_kernel, dim3(1), dim3(64), 0, stream, streams,
