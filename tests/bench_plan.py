@@ -44,6 +44,7 @@ if os.environ.get('UNIT_CLOCKS'):
     c = buf.cpu().numpy().reshape(-1, 8).astype(np.float64)
     c = c[c[:, 0] > 0]
     t0 = c[:, 0].min()
+    print('  first unit started at wall clock %d (x10 ns, mod 1e8)' % (int(t0) % 100000000))
     c = (c - t0) / 100.0       # 100 MHz wall clock -> microseconds
     names = ['start', 'heads ready', 'first phase done', 'look-back done', 'stream ready', 'done']
     print('  %d units; microseconds since the first unit started: mean / max' % len(c))

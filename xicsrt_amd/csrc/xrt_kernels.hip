@@ -2578,9 +2578,21 @@ static int bragg_element(const xrt_scene_t* sc)
         if (sc->optics[e].interact == XRT_INTERACT_CRYSTAL && (sc->optics[e].flags & XRT_F_CHECK_BRAGG)) be = e;
     return be;
 }
-// cost model of the plan, in microseconds of the whole chip (measured on MI355X)
-#define XRT_COST_JUMP_US  0.30      // one jump job
-#define XRT_COST_SKIP_US  0.54      // one workgroup walking its heads over one tile of rays / 512 stream words (latency)
+// Cost model of a plan in microseconds (measured on MI355X).  The jump kernel takes a run's jobs in
+// groups of eight: 20 us for a run's stretch + 255 us of one CU per group, spread evenly over the CUs.  A walk costs
+// latency: the unit at the end of the longest walk finishes last.
+#define XRT_COST_STRETCH_US 20.0
+#define XRT_COST_GROUP_US   255.0
+#define XRT_COST_SKIP_US    1.0     // a workgroup walking its source heads over one tile of rays (0.54 us) + what the late start costs the unit
+#define XRT_COST_SSKIP_US   0.6     // a wave walking the stream head over 512 words
+static double jump_cost_us(int n_runs, int jobs_per_run)
+{
+    // (the groups are spread evenly over the 256 CUs in shares of 1/8 - 1 group; a CU rebuilds the stretch for every run it touches)
+    const double groups = (double)n_runs * (double)((jobs_per_run + 7) / 8);
+    const double per_cu = groups / 256.0;
+    const double runs_per_cu = per_cu < 1.0 ? 1.0 : (double)n_runs / 256.0 + 1.0;
+    return XRT_COST_STRETCH_US * runs_per_cu + XRT_COST_GROUP_US * (per_cu < 0.125 ? 0.125 : per_cu) * 1.1;
+}
 static SegPlan plan_segments(const xrt_scene_t* sc, int n_runs)
 {
     SegPlan p = {1, 0, 1, 0, 0, 0, 0, 0};
@@ -2598,29 +2610,9 @@ static SegPlan plan_segments(const xrt_scene_t* sc, int n_runs)
         want = target / n_runs;
     }
     if (const char* e = getenv("XICSRT_SUBUNITS")) want_sub = atoi(e) > 0 ? atoi(e) : want_sub;
-    int64_t n = 1, len = 0, sub = 1, sublen = 0;
-    if (!(want <= 1 || N < 2 * XRT_TILE || getenv("XICSRT_NO_JUMP"))) {
-        sublen = (N + want - 1) / want;
-        if (sublen < min_len) sublen = min_len;
-        sublen = (sublen + XRT_TILE - 1) / XRT_TILE * XRT_TILE;
-        const int64_t units = (N + sublen - 1) / sublen;
-        if (want_sub > 0) sub = want_sub;
-        else {
-            // segments: jump jobs (n_heads per segment and run) against the walk of a segment's last part
-            const double nh = (double)(count_heads(sc) > 0 ? count_heads(sc) : 1);
-            const double s_opt = sqrt(((double)N / XRT_TILE) * XRT_COST_SKIP_US / (nh * (double)n_runs * XRT_COST_JUMP_US));
-            sub = (int64_t)floor((double)units / (s_opt > 1.0 ? s_opt : 1.0) + 0.5);
-        }
-        if (sub > 16) sub = 16;
-        if (sub > units) sub = units;
-        if (sub < 1) sub = 1;
-        len = sub * sublen;
-        n = (N + len - 1) / len;
-        if (n * sub <= 1 || n > 4096) { n = 1; len = 0; sub = 1; sublen = 0; }
-    }
-    if (n == 1 && sub == 1 && !gauss) return p;
-    if (n == 1 && sub == 1) { len = (N + XRT_TILE - 1) / XRT_TILE * XRT_TILE; sublen = len; }      // whole runs through the SEG kernels
-    p.n_seg = (int)n; p.seg_len = len; p.n_sub = (int)sub; p.sub_len = sublen;
+    int want_ch = 0;
+    if (const char* e = getenv("XICSRT_CHUNK_HEADS")) want_ch = atoi(e) > 0 ? atoi(e) : 0;
+    // Gaussian wavelengths: chunks of the candidate stream
     uint64_t gauss_words = 0;
     if (gauss) {
         // candidate pairs that certainly yield N/2 accepted ones (acceptance pi/4; mean + ~8 sigma + slack)
@@ -2636,17 +2628,51 @@ static SegPlan plan_segments(const xrt_scene_t* sc, int n_runs)
         p.n_gchunks = (int)((cand + per - 1) / per);
         gauss_words = 4ull * (uint64_t)p.gpairs * (uint64_t)p.n_gchunks;
     }
-    // chunk heads over the words behind the source arrays that Bragg draws can start at: [0, gauss_words + 2 N]
+    // chunk heads cover the words behind the source arrays that Bragg draws can start at: [0, gauss_words + 2 N]
     const uint64_t W = gauss_words + 2ull * (uint64_t)N;
-    if (bragg_element(sc) < 0) {
+    const bool bragg = bragg_element(sc) >= 0;
+    const int nh = count_heads(sc) > 0 ? count_heads(sc) : 1;
+    int64_t units = 1, sublen = 0;
+    const bool split = !(want <= 1 || N < 2 * XRT_TILE || getenv("XICSRT_NO_JUMP"));
+    if (split) {
+        sublen = (N + want - 1) / want;
+        if (sublen < min_len) sublen = min_len;
+        sublen = (sublen + XRT_TILE - 1) / XRT_TILE * XRT_TILE;
+        units = (N + sublen - 1) / sublen;
+    }
+    // parts per segment x chunk heads: the pair with the least jump time + longest walks
+    int64_t sub = 1;
+    int n_ch = 1;
+    {
+        double best = 1e300;
+        const int sub_lo = want_sub > 0 ? want_sub : 1, sub_hi = want_sub > 0 ? want_sub : 16;
+        for (int64_t m = sub_lo; m <= sub_hi && m <= (units > 1 ? units : 1); m++) {
+            const int64_t segs = (units + m - 1) / m;
+            const double walk = (double)(m - 1) * (double)(sublen / XRT_TILE) * XRT_COST_SKIP_US;
+            for (double c = 1.0; c <= 2048.0; c = (c < 8.0 ? c + 1.0 : floor(c * 1.25))) {
+                int ch = bragg ? (want_ch > 0 ? want_ch : (int)c) : 1;
+                const double swalk = bragg && units > 1 ? 0.75 * ((double)W / (double)ch / 512.0) * XRT_COST_SSKIP_US : 0.0;
+                const double cost = jump_cost_us(n_runs, (int)(segs * nh) + ch + p.n_gchunks) + walk + swalk;
+                if (cost < best) { best = cost; sub = m; n_ch = ch; }
+                if (!bragg || want_ch > 0) break;
+            }
+        }
+    }
+    int64_t n = 1, len = 0;
+    if (split) {
+        if (sub > units) sub = units;
+        len = sub * sublen;
+        n = (N + len - 1) / len;
+        if (n * sub <= 1 || n > 4096) { n = 1; len = 0; sub = 1; sublen = 0; }
+    } else sub = 1;
+    if (n == 1 && sub == 1 && !gauss) { p.gpairs = 0; p.n_gchunks = 0; return p; }
+    if (n == 1 && sub == 1) { len = (N + XRT_TILE - 1) / XRT_TILE * XRT_TILE; sublen = len; }      // whole runs through the SEG kernels
+    p.n_seg = (int)n; p.seg_len = len; p.n_sub = (int)sub; p.sub_len = sublen;
+    if (!bragg) {
         // no Bragg draws: only the run's last unit opens the stream, to hand it on (behind the Gaussian words)
         p.n_chunk_heads = 1; p.chunk_words = (int64_t)(W + 2);
     } else {
-        double nc = sqrt(((double)W / 512.0) * XRT_COST_SKIP_US / ((double)n_runs * XRT_COST_JUMP_US));
-        if (const char* e = getenv("XICSRT_CHUNK_HEADS")) nc = atof(e);
-        if (nc < 1.0) nc = 1.0;
-        if (nc > 2048.0) nc = 2048.0;
-        uint64_t CH = (uint64_t)((double)W / nc) + 1;
+        uint64_t CH = W / (uint64_t)n_ch + 1;
         CH = (CH + 1023) / 1024 * 1024;
         p.chunk_words = (int64_t)CH;
         p.n_chunk_heads = (int)(W / CH) + 1;
@@ -2657,12 +2683,25 @@ static bool seg_active(const SegPlan& p) { return p.n_seg > 1 || p.n_sub > 1 || 
 // jobs of a run: [segment][source head], the chunk heads, the chunk heads of the Gaussian candidate stream
 static int seg_jobs(const xrt_scene_t* sc, const SegPlan& p) { return p.n_seg * count_heads(sc) + p.n_chunk_heads + p.n_gchunks; }
 // segmented runs: [dst heads n_runs x n_jobs][polys][offsets][unit counts / flags][gauss: values, chunk counts, words]
+// the jump kernel cuts a run's groups of eight jobs into 1 - 8 shares so that every CU gets at least two work items
+static int jump_shares(int n_runs, int n_jobs)
+{
+    const long long groups = (long long)n_runs * ((n_jobs + 7) / 8);
+    int shares = 1;
+    while (shares < 8 && groups * shares < 512) shares *= 2;
+    return shares;
+}
+static size_t jump_partial_bytes(int n_runs, size_t nj)
+{
+    const int sh = jump_shares(n_runs, (int)nj);
+    return al256(sh > 1 ? sizeof(uint32_t) * 624 * nj * (size_t)n_runs * (size_t)sh : 256);
+}
 static size_t seg_bytes(const xrt_scene_t* sc, int n_runs)
 {
     const SegPlan p = plan_segments(sc, n_runs);
     if (!seg_active(p)) return 0;
     const size_t nj = (size_t)seg_jobs(sc, p);
-    size_t b = al256(sizeof(KStream) * nj * (size_t)n_runs) + al256(sizeof(uint32_t) * 624 * nj) + al256(sizeof(uint64_t) * nj)
+    size_t b = al256(sizeof(KStream) * nj * (size_t)n_runs) + jump_partial_bytes(n_runs, nj) + al256(sizeof(uint64_t) * nj)
                + al256(sizeof(uint32_t) * (size_t)n_runs * (size_t)p.n_seg * (size_t)p.n_sub) + 256;
     if (p.n_gchunks > 0)
         b += al256(sizeof(double) * (size_t)n_runs * (size_t)sc->source.intensity) + al256(sizeof(uint32_t) * (size_t)n_runs * (size_t)p.n_gchunks)
@@ -3368,29 +3407,31 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
         char* base = ws + ws_off_seg(sc, n_runs);
         KStream* dst = reinterpret_cast<KStream*>(base);
         uint32_t* d_polys = reinterpret_cast<uint32_t*>(base + al256(sizeof(KStream) * (size_t)nj * (size_t)n_runs));
-        uint64_t* d_off = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(d_polys) + al256(sizeof(uint32_t) * 624 * (size_t)nj));
+        uint64_t* d_off = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(d_polys) + jump_partial_bytes(n_runs, (size_t)nj));
         uint32_t* d_cnt = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(d_off) + al256(sizeof(uint64_t) * (size_t)nj));
         double* d_wl = reinterpret_cast<double*>(reinterpret_cast<char*>(d_cnt) + al256(sizeof(uint32_t) * (size_t)n_runs * (size_t)S * (size_t)M) + 256);
         uint32_t* d_gacc = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(d_wl) + al256(sizeof(double) * (size_t)n_runs * (size_t)N));
         uint64_t* d_gend = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(d_gacc) + al256(sizeof(uint32_t) * (size_t)n_runs * (size_t)(plan.n_gchunks > 0 ? plan.n_gchunks : 1)));
         const int n_ch = plan.n_chunk_heads, n_gch = plan.n_gchunks;
         const uint64_t GCH = 4ull * (uint64_t)plan.gpairs;
-        // polynomials + offsets of a plan live in pinned host memory and are reused by later calls
-        struct PlanCache { int64_t N, L, gpairs, CH; int S, nj, n_ch; uint32_t used; int n_arrays, ahead; uint32_t* polys; uint64_t* offs; };
+        // What the jump needs of a plan -- per group of eight jobs the positions of the polynomials' terms sorted by class
+        // (see xrt_jump_groups_kernel), and the jobs' offsets -- is derived once, kept in device memory the library owns
+        // and reused by later calls (a plan = ray count, segmentation and source arrays; not the seeds)
+        struct PlanCache { int64_t N, L, gpairs, CH; int S, nj, n_ch; uint32_t used; int n_arrays, ahead, dev; uint16_t* pos; uint32_t* cls; uint64_t* offs; };
         static std::mutex plan_mu;
         static std::vector<PlanCache> plans;
         PlanCache hit;
-        hit.polys = nullptr; hit.offs = nullptr;
+        hit.pos = nullptr; hit.cls = nullptr; hit.offs = nullptr;
+        int dev_now = 0;
+        HIP_TRY(hipGetDevice(&dev_now));
         {
             std::lock_guard<std::mutex> lock(plan_mu);
             for (const PlanCache& c : plans)
                 if (c.N == N && c.L == L && c.S == S && c.nj == nj && c.used == ks.src.array_used && c.n_arrays == ks.src.n_arrays &&
-                    c.ahead == ahead && c.n_ch == n_ch && c.gpairs == plan.gpairs && c.CH == CH) hit = c;
+                    c.ahead == ahead && c.n_ch == n_ch && c.gpairs == plan.gpairs && c.CH == CH && c.dev == dev_now) hit = c;
         }
-        if (hit.polys) {
-            HIP_TRY(hipMemcpyAsync(d_polys, hit.polys, sizeof(uint32_t) * 624 * (size_t)nj, hipMemcpyHostToDevice, stream));
-            HIP_TRY(hipMemcpyAsync(d_off, hit.offs, sizeof(uint64_t) * (size_t)nj, hipMemcpyHostToDevice, stream));
-        } else {
+        const int n_groups = (nj + XRT_JG - 1) / XRT_JG;
+        if (!hit.pos) {
         static thread_local std::vector<uint64_t> offs;
         static thread_local std::vector<uint32_t> polys;
         offs.assign((size_t)nj, 0);
@@ -3412,36 +3453,76 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
                 return fail(-5, "%s", "MT19937 characteristic polynomial could not be derived");
             for (size_t q = 0; q < Js.size(); q++) memcpy(&polys[(size_t)where[q] * 624], &tmp[q * 624], 624 * sizeof(uint32_t));
         }
+        // positions by class, every class padded to whole blocks of 16
+        std::vector<uint16_t> pos((size_t)n_groups * XRT_JG_POS_CAP, (uint16_t)XRT_JG_ZERO);
+        std::vector<uint32_t> cls((size_t)n_groups * 257, 0u);
+        {
+            std::vector<uint8_t> key(19937);
+            std::vector<uint32_t> count(256);
+            for (int g = 0; g < n_groups; g++) {
+                std::fill(key.begin(), key.end(), (uint8_t)0);
+                for (int i = 0; i < XRT_JG && XRT_JG * g + i < nj; i++) {
+                    const uint32_t* poly = &polys[(size_t)(XRT_JG * g + i) * 624];
+                    for (int jj = 0; jj < 19937; jj++) if ((poly[jj >> 5] >> (jj & 31)) & 1u) key[jj] |= (uint8_t)(1u << i);
+                }
+                std::fill(count.begin(), count.end(), 0u);
+                for (int jj = 0; jj < 19937; jj++) count[key[jj]]++;
+                uint32_t* c = &cls[(size_t)g * 257];
+                uint32_t blk = 0;
+                c[0] = 0;
+                for (int k = 1; k < 256; k++) { c[k] = blk; blk += (count[k] + 15u) / 16u; }
+                c[256] = blk;
+                if ((size_t)blk * 16 > XRT_JG_POS_CAP) return fail(-5, "%s", "jump position table overflow");
+                std::vector<uint32_t> at(256);
+                for (int k = 1; k < 256; k++) at[k] = c[k] * 16u;
+                uint16_t* pp = &pos[(size_t)g * XRT_JG_POS_CAP];
+                for (int jj = 0; jj < 19937; jj++) if (key[jj]) pp[at[key[jj]]++] = (uint16_t)jj;
+            }
+        }
         PlanCache c;
         c.N = N; c.L = L; c.S = S; c.nj = nj; c.used = ks.src.array_used; c.n_arrays = ks.src.n_arrays; c.ahead = ahead;
-        c.n_ch = n_ch; c.gpairs = plan.gpairs; c.CH = CH;
-        c.polys = nullptr; c.offs = nullptr;
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c.polys), sizeof(uint32_t) * 624 * (size_t)nj, hipHostMallocDefault));
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c.offs), sizeof(uint64_t) * (size_t)nj, hipHostMallocDefault));
-        memcpy(c.polys, polys.data(), sizeof(uint32_t) * 624 * (size_t)nj);
-        memcpy(c.offs, offs.data(), sizeof(uint64_t) * (size_t)nj);
-        HIP_TRY(hipMemcpyAsync(d_polys, c.polys, sizeof(uint32_t) * 624 * (size_t)nj, hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipMemcpyAsync(d_off, c.offs, sizeof(uint64_t) * (size_t)nj, hipMemcpyHostToDevice, stream));
+        c.n_ch = n_ch; c.gpairs = plan.gpairs; c.CH = CH; c.dev = dev_now;
+        c.pos = nullptr; c.cls = nullptr; c.offs = nullptr;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c.pos), pos.size() * sizeof(uint16_t)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c.cls), cls.size() * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c.offs), sizeof(uint64_t) * (size_t)nj));
+        // (host temporaries: synchronous copies, once per plan)
+        HIP_TRY(hipMemcpy(c.pos, pos.data(), pos.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c.cls, cls.data(), cls.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c.offs, offs.data(), sizeof(uint64_t) * (size_t)nj, hipMemcpyHostToDevice));
         {
             std::lock_guard<std::mutex> lock(plan_mu);
-            if (plans.size() >= 64) {       // oldest plan out (its buffers may still be in flight: sync first)
-                (void)hipStreamSynchronize(stream);
-                (void)hipHostFree(plans.front().polys); (void)hipHostFree(plans.front().offs);
+            if (plans.size() >= 64) {       // oldest plan out (a launch may still be reading its tables: wait for the device first)
+                (void)hipDeviceSynchronize();
+                (void)hipFree(plans.front().pos); (void)hipFree(plans.front().cls); (void)hipFree(plans.front().offs);
                 plans.erase(plans.begin());
             }
             plans.push_back(c);
         }
+        hit = c;
         }
-        KJumpJobs jobs;
-        jobs.polys = d_polys; jobs.offsets = d_off; jobs.dst = dst; jobs.n_jobs = nj; jobs.n_runs = n_runs;
+        KJumpGroups jobs;
+        jobs.pos = hit.pos; jobs.cls = hit.cls; jobs.offsets = hit.offs; jobs.dst = dst; jobs.n_jobs = nj; jobs.n_runs = n_runs;
         jobs.ahead = (uint64_t)ahead;
-        const size_t jl = sizeof(uint32_t) * ((size_t)XRT_STRETCH + 48 + 624);
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(xrt_jump_jobs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)jl));
-        int gy = (512 + n_runs - 1) / n_runs;
-        if (gy > nj) gy = nj;
-        if (gy < 1) gy = 1;
-        hipLaunchKernelGGL(xrt_jump_jobs_kernel, dim3(n_runs, gy), dim3(XRT_JUMP_THREADS), jl, stream, streams, jobs);
-        HIP_TRY(hipGetLastError());
+        const size_t jl = sizeof(uint32_t) * ((size_t)XRT_JG_S_WORDS + XRT_JG * XRT_JG_OUT + 264);
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(xrt_jump_groups_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)jl));
+        // One workgroup per CU (105 KB of LDS), each with an equal share of the work items (run, group, share of the
+        // group's classes); the groups are cut into 1 - 8 shares so that a workgroup gets at least two items
+        {
+            static thread_local int c_dev2 = -1, c_cus2 = 256;
+            if (c_dev2 != dev_now) { HIP_TRY(hipDeviceGetAttribute(&c_cus2, hipDeviceAttributeMultiprocessorCount, dev_now)); c_dev2 = dev_now; }
+            const int shares = jump_shares(n_runs, nj);
+            jobs.n_shares = shares; jobs.pad = 0;
+            jobs.partial = reinterpret_cast<uint32_t*>(d_polys);       // (behind the destination heads)
+            const long long items = (long long)n_runs * n_groups * shares;
+            const int grid = (int)(items < c_cus2 ? items : c_cus2);
+            hipLaunchKernelGGL(xrt_jump_groups_kernel, dim3((unsigned)grid), dim3(XRT_JUMP_THREADS), jl, stream, streams, jobs);
+            HIP_TRY(hipGetLastError());
+            if (shares > 1) {
+                hipLaunchKernelGGL(xrt_jump_combine_kernel, dim3((unsigned)(n_runs * nj)), dim3(640), 0, stream, streams, jobs);
+                HIP_TRY(hipGetLastError());
+            }
+        }
         a.streams = streams; a.heads = dst; a.n_runs = n_runs; a.n_src_heads = nh;
         a.run_counter = reinterpret_cast<uint32_t*>(ws);
         a.progress = env_on("XICSRT_NO_PRIORITY_FEEDBACK") ? nullptr : reinterpret_cast<unsigned long long*>(ws + 32);
@@ -3576,6 +3657,13 @@ static int trace_runs(const xrt_scene_t* sc, const uint32_t* seeds, int32_t n_ru
     char* ws = reinterpret_cast<char*>(workspace);
     uint32_t* d_seeds = reinterpret_cast<uint32_t*>(ws + ws_off_seeds(sc));
     KStream* streams = reinterpret_cast<KStream*>(ws + ws_off_streams(sc, n_runs));
+    if (n_runs <= 512) {
+        // (few seeds: through the kernel-argument path like the scene, no staged copy from pageable memory)
+        KBlob b;
+        memcpy(b.w, seeds, sizeof(uint32_t) * (size_t)n_runs);
+        hipLaunchKernelGGL(xrt_put_kernel, dim3(1), dim3(256), 0, stream, d_seeds, b, n_runs);
+        HIP_TRY(hipGetLastError());
+    } else
     HIP_TRY(hipMemcpyAsync(d_seeds, seeds, sizeof(uint32_t) * (size_t)n_runs, hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(xrt_seed_kernel, dim3(n_runs), dim3(64), 0, stream, d_seeds, streams,
                        reinterpret_cast<KState*>(ws + ws_off_gauss(sc, n_runs)), n_runs);
