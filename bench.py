@@ -164,6 +164,35 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    if use_dist and dist.get_world_size() != args.gpus:
+        # a line for N GPUs must come from N ranks: refuse rather than print a number that is not what it says
+        if rank == 0:
+            sys.stderr.write('bench.py: --gpus %d but the process group has %d ranks; no line printed\n'
+                             % (args.gpus, dist.get_world_size()))
+        dist.destroy_process_group()
+        sys.exit(2)
+    if not use_dist and args.gpus != 1:
+        sys.stderr.write('bench.py: --gpus %d needs one process per GPU (torch.distributed.run); no line printed\n' % args.gpus)
+        sys.exit(2)
+
+    # What users call: xicsrt_amd.raytrace(config) of the same scene (keep_history=False), whole call on the host clock,
+    # and the part of it that is object construction (SURVEY 8d prices the call without it).  Outside the timed region.
+    call_ms = setup_ms = None
+    if rank == 0 and not use_dist:
+        import copy
+        cfg_user = spectrometer_config(args.rays, total_runs)
+        xrt.raytrace(copy.deepcopy(cfg_user))                      # warm-up (plans, workspace)
+        best = 1e30
+        for _ in range(3):
+            t1 = time.perf_counter(); xrt.raytrace(copy.deepcopy(cfg_user)); best = min(best, time.perf_counter() - t1)
+        call_ms = best * 1e3
+        best = 1e30
+        for _ in range(3):
+            t1 = time.perf_counter()
+            c2, e2 = xrt._prepare(copy.deepcopy(cfg_user)); f2 = e2.flatten(); xrt.DeviceTrace(f2)
+            best = min(best, time.perf_counter() - t1)
+        setup_ms = best * 1e3
+
     if rank == 0:
         photons_per_step = float(total_runs) * float(args.rays)
         ms_per_step = elapsed / max(args.steps, 1) * 1e3
@@ -176,6 +205,7 @@ def main():
             'metric': 'Mphotons/sec (launched->detector) 3-element crystal spectrometer',
             'value': value, 'unit': 'Mphotons/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
+            'raytrace_call_ms': call_ms, 'raytrace_call_object_construction_ms': setup_ms,
             'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'cfg3: XicsrtSourceDirected(point, spread 10deg) -> XicsrtOpticSphericalCrystal'
                                    '(gaussian rocking curve) -> XicsrtOpticDetector; %d rays/run x %d runs/GPU, '
@@ -190,7 +220,7 @@ def main():
                          'algorithmic_bytes_per_photon': ALGO_BYTES_PER_PHOTON,
                          'photons_per_launch': per_launch_photons},
         }
-        prof, prof_file = committed_profile(args.rays, args.runs)
+        prof, prof_file = committed_profile(args.rays, len(my_seeds))
         if prof is not None:
             # `frac` above prices the ALGORITHMIC bytes (what a ray-SoA-in-HBM design would move); the fused
             # kernel keeps rays in registers / LDS, so the bytes that really cross the HBM interface are the

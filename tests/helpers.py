@@ -190,6 +190,7 @@ class OracleDeviceTrace:
             self.images += self.torch.from_numpy(img)
 
     def trace_history(self, state, keep_images=True, all_rays=False, on_device=False):
+        self.raise_status()         # (DeviceTrace.trace_history reads the device status of every call on the spot)
         key, pos, has_gauss, gauss = state
         st = xscene.RngState()
         C.memmove(st.key, np.ascontiguousarray(key, dtype=np.uint32).ctypes.data, 624 * 4)

@@ -138,9 +138,13 @@ def test_raytrace_under_a_process_group_equals_single_process(tmp_path, keep_his
     assert len([f for f in os.listdir(tmp_path / 'two') if 'config' in f]) == 1
 
 
-def test_every_rank_raises_when_one_device_reports_an_error(tmp_path):
+@pytest.mark.parametrize('keep_history', [False, True])
+def test_every_rank_raises_when_one_device_reports_an_error(tmp_path, keep_history):
+    """One rank's device reports 'intensity of less than one'.  Without histories the status is read behind the runs;
+    with keep_history `trace_history` raises inside the run loop, in front of every collective: either way the
+    failing rank raises the reference's exception, the other one a RuntimeError, nobody hangs, nothing is saved."""
     (tmp_path / 'err').mkdir()
-    res = _spawn(_raytrace_worker, 2, _config(tmp_path / 'err', False), 1)
+    res = _spawn(_raytrace_worker, 2, _config(tmp_path / 'err', keep_history), 1)
     assert res[1][0] == 'raised' and res[1][1] == 'ValueError' and 'intensity of less than one' in res[1][2]
     assert res[0][0] == 'raised' and res[0][1] == 'RuntimeError'
     assert os.listdir(tmp_path / 'err') == []

@@ -261,6 +261,29 @@ def test_intersect_check_bounds_interact_as_separate_calls(name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('name', helpers.golden_names('steps'))
+def test_interact_updates_a_separate_mask_array_in_place(name):
+    """interact(rays, xloc, norm, mask) with a mask array of the caller's own: the reference thins it out in place
+    (InteractCrystal.angle_check, _InteractCrystal.py:128) and makes it rays['mask'] (:93); mirrors and plain elements
+    copy it into rays['mask'] (_InteractMirror.py:25-26)."""
+    import xicsrt_amd
+    cfg, gold = helpers.load_golden(name)
+    np.random.seed(cfg['general']['random_seed'])
+    source = xicsrt_amd.get_element(cfg, 'source')
+    crystal = xicsrt_amd.get_element(cfg, 'crystal')
+    rays = source.generate_rays()
+    rays['mask'][::7] = False
+    xloc, norm, mask = crystal.intersect(rays)
+    mask = crystal.check_bounds(xloc, mask)
+    own = mask.copy()
+    rays = crystal.interact(rays, xloc, norm, own)
+    assert np.array_equal(own, gold['out/mask']) and np.array_equal(rays['mask'], gold['out/mask'])
+    if crystal.interact_kind == 'crystal':
+        assert rays['mask'] is own
+    assert np.random.random_sample() == float(gold['next_double'])
+
+
+@pytest.mark.gpu
 def test_integrated_test_00_photon_accounting():
     """The reference's own assertion (testing/integrated_test_00.ipynb): a 1 cm^3 plasma cube of emissivity
     1e12 emits 1e6 photons into the full sphere; half of them (within 5 sigma) cross the detector plane."""

@@ -522,3 +522,29 @@ def test_runs_just_above_the_resident_workgroups_split_off_a_tail(monkeypatch):
     assert np.array_equal(n_split, n_whole) and np.array_equal(i_split, i_whole)
     n_cpu, i_cpu = helpers.oracle_counts(flat, seeds, 2, threads=16)
     assert np.array_equal(n_split, n_cpu) and np.array_equal(i_split[:flat.image_bins], i_cpu[:flat.image_bins])
+
+
+@pytest.mark.gpu
+def test_tail_pass_fits_the_workspace_on_a_narrow_grid(monkeypatch):
+    """A launch grid of 512 workgroups (two per CU, what the mesh / local-frame variant gets; forced here) leaves
+    the last 2 of 514 runs to a second pass, which is segmented and lays the workspace out differently (more heads per
+    run, jump tables): xrt_workspace_bytes covers that layout too, and the result equals the oracle's."""
+    monkeypatch.setenv('XICSRT_MAX_WG_PER_CU', '2')
+    import bench
+    config = xconfig.get_config(bench.spectrometer_config(200000, 514, seed=11))
+    flat = xrt.Elements(config).flatten()
+    seeds = xrt.run_seeds(11, 514)
+    lib = capi.lib()
+    # (the second pass parks its candidates in HBM when they fit a 2 GiB share of the workspace -- here they do -- and
+    #  counts in a pass of its own otherwise; both layouts are inside what the library asks for)
+    assert lib.xrt_workspace_bytes(flat.byref(), 514) >= lib.xrt_workspace_bytes(flat.byref(), 2)
+    dev = xrt.DeviceTrace(flat)
+    lib.xrt_last_path(1)
+    dev.trace(seeds, 1, keep_images=True)
+    meta, image = dev.results()
+    assert lib.xrt_last_path(1) & capi.PATH_SEGMENTED             # the tail went the segmented way
+    o_num, o_img = helpers.oracle_counts(flat, seeds, 1, threads=16)
+    assert [int(meta[nm]['num_out']) for nm in flat.names] == [int(v) for v in o_num]
+    got = np.concatenate([image[nm].ravel() for nm in flat.names[1:]]).astype(np.int64)
+    assert np.array_equal(got, o_img[:flat.image_bins])
+

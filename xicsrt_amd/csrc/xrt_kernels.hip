@@ -2711,7 +2711,7 @@ static size_t seg_bytes(const xrt_scene_t* sc, int n_runs)
 // One-pass segmented runs park every unit's Bragg candidates in HBM: per run and ray of capacity 7 doubles, the ray
 // index and the hit face (64 B).  At the end of the workspace; beyond the budget the two-pass route is taken.
 #define XRT_CAND_BUDGET      (48ull << 30)
-#define XRT_CAND_BUDGET_TAIL (8ull << 30)       // for the < 256 runs an unsegmented launch leaves to a second pass
+#define XRT_CAND_BUDGET_TAIL (2ull << 30)       // for the < 256 runs an unsegmented launch leaves to a second pass
 static size_t cand_capacity(const xrt_scene_t* sc) { return ((size_t)(sc->source.intensity > 0 ? sc->source.intensity : 1) + 255) & ~(size_t)255; }
 static size_t cand_bytes(const xrt_scene_t* sc, int n_runs, size_t budget)
 {
@@ -3014,10 +3014,14 @@ static int upload_meshes(const xrt_scene_t* sc, char* ws, int n_runs, KScene* ks
         k.interpolate = m->interpolate; k.n_simplices = m->n_simplices;
         char* p = base + al256(sizeof(KMesh));
         // synchronous copies throughout: the packed tables are host temporaries
+        hipError_t put_err = hipSuccess;        // (the first failed copy; checked behind the last one)
         auto put = [&](const void* src, size_t bytes) -> uintptr_t {
             char* dst = p;
             p += al256(bytes > 0 ? bytes : 8);
-            if (src && bytes) (void)hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+            if (src && bytes) {
+                const hipError_t e = hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+                if (e != hipSuccess && put_err == hipSuccess) put_err = e;
+            }
             return (uintptr_t)dst;
         };
         const size_t P = (size_t)m->n_points, F = (size_t)m->n_faces, Cn = (size_t)m->n_coarse_faces, T = (size_t)m->n_simplices;
@@ -3123,6 +3127,7 @@ static int upload_meshes(const xrt_scene_t* sc, char* ws, int n_runs, KScene* ks
                 k.cells = (const XRT_G1 d4v*)put(cells.data(), cells.size() * sizeof(KCellRec));
             }
         }
+        if (put_err != hipSuccess) return fail(-10, "copy of the mesh tables to the device: %s", hipGetErrorString(put_err));
         HIP_TRY(hipMemcpy(base, &k, sizeof(KMesh), hipMemcpyHostToDevice));
         ks->opt[e].mesh = reinterpret_cast<const KMesh*>(base);
         base += mesh_bytes(m);
@@ -3422,6 +3427,7 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
         static std::vector<PlanCache> plans;
         PlanCache hit;
         hit.pos = nullptr; hit.cls = nullptr; hit.offs = nullptr;
+        bool plan_once = false;
         int dev_now = 0;
         HIP_TRY(hipGetDevice(&dev_now));
         {
@@ -3491,13 +3497,10 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
         HIP_TRY(hipMemcpy(c.cls, cls.data(), cls.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c.offs, offs.data(), sizeof(uint64_t) * (size_t)nj, hipMemcpyHostToDevice));
         {
+            // (cached plans are never freed: another thread may be about to launch with them; the cache is bounded
+            //  instead, and a plan beyond the bound is released by this call once its launch is through)
             std::lock_guard<std::mutex> lock(plan_mu);
-            if (plans.size() >= 64) {       // oldest plan out (a launch may still be reading its tables: wait for the device first)
-                (void)hipDeviceSynchronize();
-                (void)hipFree(plans.front().pos); (void)hipFree(plans.front().cls); (void)hipFree(plans.front().offs);
-                plans.erase(plans.begin());
-            }
-            plans.push_back(c);
+            if (plans.size() < 256) plans.push_back(c); else plan_once = true;
         }
         hit = c;
         }
@@ -3521,6 +3524,10 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
             if (shares > 1) {
                 hipLaunchKernelGGL(xrt_jump_combine_kernel, dim3((unsigned)(n_runs * nj)), dim3(640), 0, stream, streams, jobs);
                 HIP_TRY(hipGetLastError());
+            }
+            if (plan_once) {
+                HIP_TRY(hipStreamSynchronize(stream));
+                (void)hipFree(hit.pos); (void)hipFree(hit.cls); (void)hipFree(hit.offs);
             }
         }
         a.streams = streams; a.heads = dst; a.n_runs = n_runs; a.n_src_heads = nh;
@@ -3701,7 +3708,9 @@ extern "C" int xrt_trace(const xrt_scene_t* sc, const uint32_t* seeds, int32_t n
     if (st) return st;
     if (n_runs <= 0 || n_iter <= 0) return 0;
     if (!seeds || !num_out || !workspace) return fail(-1, "%s", "NULL argument");
-    if (workspace_bytes < xrt_workspace_bytes(sc, n_runs)) return fail(-4, "%s", "workspace too small");
+    // (the layout of this call; xrt_workspace_bytes() also covers the layouts of the possible second pass, which is
+    //  checked when its run count is known -- a sweep over all of them here would cost a millisecond per call)
+    if (workspace_bytes < ws_base_bytes(sc, n_runs)) return fail(-4, "%s", "workspace too small");
     // (see t_tail: the unsegmented launch may leave the last < 256 runs to a second pass over the same workspace)
     // (a second pass costs about a millisecond of set-up: only where a run takes longer than that)
     t_tail = tail_split_possible(sc) ? 0 : -1;

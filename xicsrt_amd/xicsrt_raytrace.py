@@ -251,7 +251,14 @@ class DeviceTrace:
         self._ws = None
 
     def _workspace(self, n_runs):
-        need = int(self.lib.xrt_workspace_bytes(self.flat.byref(), n_runs))
+        # (the size depends on the scene, the run count and the library's route switches; above 256 runs the library
+        #  sweeps the layouts of every possible second pass, a millisecond of host time: asked once per case)
+        key = (n_runs,) + tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith('XICSRT_')))
+        if not hasattr(self, '_ws_need'):
+            self._ws_need = {}
+        need = self._ws_need.get(key)
+        if need is None:
+            need = self._ws_need[key] = int(self.lib.xrt_workspace_bytes(self.flat.byref(), n_runs))
         if self._ws is None or self._ws.numel() < need:
             self._ws = self.torch.empty(max(need, 16), dtype=self.torch.uint8, device=self.dev)
         return self._ws, need
@@ -656,15 +663,34 @@ def raytrace(config):
     indices = shard_runs(num_runs, rank, world)
 
     # per-run image files carry the run number in their names: each rank writes those of its own runs
-    run_outputs, device, cfg = _raytrace_runs(copy.deepcopy(config_in), indices, seeds, internal=True,
-                                              per_run_images=bool(general['save_images']))
+    failure = None
+    run_outputs = device = cfg = None
+    try:
+        run_outputs, device, cfg = _raytrace_runs(copy.deepcopy(config_in), indices, seeds, internal=True,
+                                                  per_run_images=bool(general['save_images']))
+    except Exception as exc:        # noqa: BLE001
+        # Under a process group nothing may be raised on one rank alone: the others would sit in the next collective
+        # until the watchdog fires.  (With keep_history / save_images the device status is read run by run, in front
+        # of any collective: 'intensity of less than one', a plasma over its capacity ...)  The exception travels to the
+        # status agreement below and is raised there, on every rank.
+        if not distributed:
+            raise
+        failure = exc
 
-    t = device.torch
     if distributed:
-        code, message = device.status()
-        flag = t.tensor([1 if code != 0 else 0], dtype=t.int64, device=device.num_out.device)
+        import torch as t
+        code, message = (0, '')
+        if failure is None:
+            code, message = device.status()
+        if device is not None:
+            where = device.num_out.device
+        else:
+            where = t.device('cuda', t.cuda.current_device()) if dist.get_backend() == 'nccl' else t.device('cpu')
+        flag = t.tensor([1 if (code != 0 or failure is not None) else 0], dtype=t.int64, device=where)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         if int(flag.item()) != 0:
+            if failure is not None:
+                raise failure
             raise_device_status(code, message)
             raise RuntimeError('another rank reported a device error; results are not valid')
         packed = pack_counts(device.num_out, device.images)
@@ -683,6 +709,7 @@ def raytrace(config):
                     single[group]['history'] = payload[group]
                 run_outputs.append((i, single))
     else:
+        t = device.torch
         meta, image = device.results()
 
     output = _empty_output(cfg)
@@ -885,6 +912,14 @@ def optic_interact(optic_obj, rays, xloc, norm, mask=None):
     rays['origin'][:] = out[0:3, :n].T
     rays['direction'][:] = out[3:6, :n].T
     new_mask = d_m.cpu().numpy().astype(bool)
+    # The reference's interact() works on the caller's mask array in place: InteractCrystal.angle_check thins it out
+    # (`m[m] &= ...`, _InteractCrystal.py:128) and interact() then makes it rays['mask'] (:93); InteractNone / Mirror
+    # copy it into rays['mask'] (_InteractObject.py:32-33, _InteractMirror.py:25-26).
+    if isinstance(mask, np.ndarray) and mask is not rays['mask'] and mask.shape == new_mask.shape:
+        mask[:] = new_mask
+        if o.interact == xscene.INTERACT['crystal']:
+            rays['mask'] = mask
+            return rays
     if isinstance(rays['mask'], np.ndarray) and rays['mask'].shape == new_mask.shape:
         rays['mask'][:] = new_mask
     else:
