@@ -9,8 +9,8 @@ runs = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 rays = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000
 rep = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 lib = capi.lib()
-for tag in ('flat', 'interp'):
-    cfg, _ = helpers.load_golden('E_cfg5_mesh_%s_1e5' % tag)
+for tag in ('flat', 'interp', 'norefine', '81_coarse17'):
+    cfg, _ = helpers.load_golden('E_cfg5_mesh_%s_1e5' % tag if tag in ('flat', 'interp') else 'E_mesh_%s_counts' % tag)
     cfg = copy.deepcopy(cfg)
     cfg['general'].update(number_of_runs=runs, number_of_iter=1, keep_history=False)
     cfg['sources']['source']['intensity'] = rays
@@ -29,7 +29,7 @@ for tag in ('flat', 'interp'):
         if best is None or dt < best[0]:
             best = (dt, ms.value, n.value)
     meta, image = dev.results()
-    print(json.dumps({'scene': 'cfg5 41x41 toroidal mesh crystal', 'mesh_interpolate': tag == 'interp', 'runs': runs,
+    print(json.dumps({'scene': 'cfg5 41x41 toroidal mesh crystal', 'mesh': tag, 'runs': runs,
                       'rays_per_run': rays, 'call_s': best[0], 'kernel_ms': best[1], 'launches': best[2],
                       'Mphot_s': runs * rays / best[0] / 1e6,
                       'num_out': {nm: int(meta[nm]['num_out']) for nm in flat.names}}), flush=True)

@@ -80,6 +80,7 @@ def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
     bad, skipped, paths, t0 = 0, 0, {}, time.time()
+    outliers = []            # decisions equal, a position beyond 1e-9 (and inside the task's 1e-6): listed, not counted as mismatches
     for case in range(n_cases):
         rs = np.random.RandomState(seed0 + case)
         cfg = scene(rs)
@@ -127,7 +128,11 @@ def main():
                 if both.any():
                     # (1e-9: a lost ray that grazes the next plane is recorded hundreds of metres away, where last-ulp
                     #  differences of the reflected direction show at 1e-11; the fixed tests hold the goldens to 1e-12)
-                    ok = np.max(np.abs(rays[both] - o_rays[both])) <= 1e-9 * max(1.0, float(np.max(np.abs(o_rays[both]))))
+                    rel = float(np.max(np.abs(rays[both] - o_rays[both]))) / max(1.0, float(np.max(np.abs(o_rays[both]))))
+                    if rel > 1e-6:
+                        ok = False
+                    elif rel > 1e-9:
+                        outliers.append({'case': seed0 + case, 'relative_error': rel, 'largest_coordinate': float(np.max(np.abs(o_rays[both])))})
                 rs2 = np.random.RandomState(0)
                 rs2.set_state(('MT19937',) + tuple(st))
                 ok = ok and rs2.random_sample() == helpers.state_next_double(o_st)
@@ -136,8 +141,10 @@ def main():
             print(json.dumps({'case': seed0 + case, 'gpu': n_gpu.tolist(), 'oracle': [int(v) for v in n_cpu], 'env': env, 'config': cfg}), flush=True)
         if case % 50 == 49:
             print('# %d cases, %d mismatches, %.0f s' % (case + 1, bad, time.time() - t0), flush=True)
-    print(json.dumps({'cases': n_cases, 'first_seed': seed0, 'skipped': skipped, 'mismatches': bad, 'scenes': paths,
-                      'seconds': time.time() - t0}))
+    # decision_mismatches: counters, pixels, masks, NaN patterns, stream positions or a position beyond 1e-6 -- must be 0;
+    # position_outliers: all decisions equal, a position differs by 1e-9 .. 1e-6 relative (ill-conditioned lost rays)
+    print(json.dumps({'cases': n_cases, 'first_seed': seed0, 'skipped': skipped, 'decision_mismatches': bad,
+                      'position_outliers': outliers, 'scenes': paths, 'seconds': time.time() - t0}))
 
 
 if __name__ == '__main__':

@@ -394,6 +394,14 @@ def build_cases():
                                                                                                      bundle_volume=0.001 / 400),
                                                          seed=78, runs=2, iters=2))
 
+    # --- the two scenes of the randomised sweep (profiles/r02_fuzz_parity_c.json, seeds 9011073 / 9015074) where device and
+    #     oracle differed beyond 1e-9 in the position of a LOST ray: a ray recorded 24 km away (it grazes the next plane) and a
+    #     ray on a double root of the torus quartic.  Inputs: tests/golden/fuzz_outliers.json, written by tests/fuzz_parity.scene()
+    for seed, c in sorted(json.load(open(os.path.join(HERE, 'fuzz_outliers.json'))).items()):
+        c = copy.deepcopy(c)
+        c['general'].update(keep_history=True, number_of_iter=1, number_of_runs=1)
+        add('Y_fuzz_%s_trace' % seed, 'trace', c)
+
     # --- the reference's own integrated tests (testing/integrated_test_01 / _02 .ipynb): one base config,
     #     crystal class swapped, non-strict config check with keys that most classes do not know ------------
     def integrated(radius, rmaj, rmin, fwhm, spread_deg, size, src_size, n):
@@ -458,6 +466,16 @@ def build_cases():
                      **dict(_BRAGG, check_bragg=False))
         tag = 'interp' if interp else 'flat'
         add('E_mesh_%s_trace' % tag, 'trace', cfg_three(500, c, history=True, seed=71))
+    # first passes over many faces (the device then goes through an x-y grid of the faces): the fine 41 x 41 mesh searched
+    # directly (mesh_refine off: 3200 faces), and an 81 x 81 mesh behind a 17 x 17 coarse level (512 faces)
+    c = _crystal('XicsrtOpticMeshToroidalCrystal', radius_major=1.0, radius_minor=0.2, mesh_size=[41, 41], mesh_refine=False,
+                 **dict(_BRAGG, rocking_fwhm=2e-3))
+    add('E_mesh_norefine_counts', 'counts', cfg_three(20000, c, seed=75, runs=2))
+    add('E_mesh_norefine_trace', 'trace', cfg_three(600, dict(c, check_bragg=False), history=True, seed=75))
+    c = _crystal('XicsrtOpticMeshToroidalCrystal', radius_major=1.0, radius_minor=0.2, mesh_size=[81, 81], mesh_coarse_size=[17, 17],
+                 **dict(_BRAGG, rocking_fwhm=2e-3))
+    add('E_mesh_81_coarse17_counts', 'counts', cfg_three(20000, c, seed=76, runs=2))
+    add('E_mesh_81_coarse17_trace', 'trace', cfg_three(600, dict(c, check_bragg=False), history=True, seed=76))
     # tiny and lopsided meshes: one quad (two faces) with the coarse level as fine as the fine one, a 3 x 2 grid,
     # a coarse mesh finer than the fine mesh, many thin columns (the nearest-point buckets degenerate)
     for tag, size, coarse, interp in (('2x2', [2, 2], [2, 2], False), ('3x2', [3, 2], [2, 2], True), ('coarse_finer', [4, 4], [9, 9], False),

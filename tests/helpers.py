@@ -137,10 +137,16 @@ def split_images(flat, images):
 # 1.6e-11 there (masks and counts are identical).
 RTOL_DEFAULT = 1e-12
 RTOL_CASE = {'I2_ToroidalCrystal_trace': 1e-9}
+# The Y_fuzz cases (found by tests/fuzz_parity.py): the position of ONE LOST ray each -- a ray that grazes the next plane
+# and is recorded 24 km away, a ray on a double root of the torus quartic.  The oracle (libm) agrees with the reference to
+# 7e-13 there; the device (its own square roots, divisions and last-ulp transcendental differences, amplified by the
+# ill-conditioned point) to 1.7e-9 and 1.3e-8.  Masks, counters and pixels are equal; the task's bound is 1e-6.
+RTOL_CASE_DEVICE = {'Y_fuzz_9011073_trace': 1e-7, 'Y_fuzz_9015074_trace': 1e-7}
 
 
-def rtol_for(name):
-    return RTOL_CASE.get(name, RTOL_DEFAULT)
+def rtol_for(name, device=False):
+    tol = RTOL_CASE.get(name, RTOL_DEFAULT)
+    return max(tol, RTOL_CASE_DEVICE.get(name, 0.0)) if device else tol
 
 
 def assert_history_matches_golden(flat, rays, mask, gold, rtol=1e-12):

@@ -55,7 +55,7 @@ def test_history_matches_reference_and_oracle(name, devlib):
     for nm in flat.names[1:]:
         if image[nm] is not None:
             assert np.array_equal(image[nm].astype(np.int64), gold['image/' + nm]), 'image ' + nm
-    helpers.assert_history_matches_golden(flat, rays, mask, gold, rtol=max(FLOAT_RTOL, helpers.rtol_for(name)))
+    helpers.assert_history_matches_golden(flat, rays, mask, gold, rtol=max(FLOAT_RTOL, helpers.rtol_for(name, device=True)))
     rs = np.random.RandomState(0)
     rs.set_state(('MT19937',) + tuple(st_out))
     assert rs.random_sample() == float(gold['next_double'])
@@ -65,7 +65,7 @@ def test_history_matches_reference_and_oracle(name, devlib):
     both = ~np.isnan(o_rays)
     assert np.array_equal(np.isnan(o_rays), np.isnan(rays))
     err = np.max(np.abs(o_rays[both] - rays[both])) if both.any() else 0.0
-    assert err <= max(FLOAT_RTOL, helpers.rtol_for(name)) * max(1.0, float(np.max(np.abs(o_rays[both])))) if both.any() else True
+    assert err <= max(FLOAT_RTOL, helpers.rtol_for(name, device=True)) * max(1.0, float(np.max(np.abs(o_rays[both])))) if both.any() else True
 
 
 @pytest.mark.parametrize('name', _cases('counts'))

@@ -437,6 +437,28 @@ def test_cfg5_toroidal_mesh_crystal_41x41_1e9_photons(tag):
     assert np.array_equal(n_gpu, n_cpu) and np.array_equal(i_gpu[:flat.image_bins], i_cpu[:flat.image_bins])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['E_mesh_norefine_counts', 'E_mesh_81_coarse17_counts'])
+def test_meshes_with_many_first_pass_faces_at_full_size(name, monkeypatch):
+    """First passes over 3200 faces (41 x 41, mesh_refine off) and 512 faces (81 x 81 behind a 17 x 17 coarse level),
+    1000 runs x 1e6 rays: the device finds a ray's faces through an x-y grid over them; the same integers as the walk
+    over every face, the oracle's on a few runs, the reference's on the small golden."""
+    config, elements, flat = helpers.build(_full_size(name, 1000, {'intensity': 1000000}))
+    seeds = xrt.run_seeds(config['general']['random_seed'], 1000)
+    n_all, i_all = _trace(flat, seeds)
+    assert int(n_all[0]) == 10 ** 9
+    off, nx, ny = flat.image_slices['detector']
+    assert int(i_all[off:off + nx * ny].sum()) == int(n_all[2])
+    n_gpu, i_gpu = _trace(flat, seeds[:3])
+    n_cpu, i_cpu = helpers.oracle_counts(flat, seeds[:3], 1, threads=3)
+    assert np.array_equal(n_gpu, n_cpu) and np.array_equal(i_gpu[:flat.image_bins], i_cpu[:flat.image_bins])
+    monkeypatch.setenv('XICSRT_NO_FACE_GRID', '1')
+    n_walk, i_walk = _trace(flat, seeds[:40])
+    monkeypatch.delenv('XICSRT_NO_FACE_GRID')
+    n_grid, i_grid = _trace(flat, seeds[:40])
+    assert np.array_equal(n_walk, n_grid) and np.array_equal(i_walk, i_grid)
+
+
 def test_plasma_runs_in_several_batches(monkeypatch):
     """More runs than run slots for the scout's stream dumps: batches of slots, same integers."""
     cfg, gold = helpers.load_golden('F_cfg4_plasma_counts')

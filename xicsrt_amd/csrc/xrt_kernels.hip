@@ -126,6 +126,20 @@ struct KMesh {               // device pointers, see xrt_mesh_t
     double  grid_x0, grid_y0, grid_hx, grid_hy, grid_ihx, grid_ihy, grid_tiny;
     gdp points;                     // [n_points][3] (search without a grid)
     const XRT_G1 d4v* cells;        // KCellRec [nx*ny] first point of every bucket (idx -1: empty), then the chained ones
+    // x-y grid over the faces of the first pass (built by the library; fg_n = 0: none, every face is walked).  A ray
+    // crosses the slab fg_zlo .. fg_zhi that holds all those faces along a short stretch; only the faces of the cells
+    // under that stretch can be hit.  fg_nbar / fg_sin: every face normal lies within a cone about nbar, and a ray whose
+    // direction is at least fg_sin (sine) away from the plane normal to nbar is not nearly parallel to any face.
+    int32_t fg_n, fg_pad;
+    double  fg_x0, fg_y0, fg_ihx, fg_ihy, fg_zlo, fg_zhi, fg_margin, fg_nbar[3], fg_sin;
+    gip fg_start, fg_faces;         // [fg_n * fg_n + 1] first entry of a cell's face list, [..] the lists (ascending face index)
+    gdp fg_zcell;                   // [fg_n * fg_n][2] the slab of z that holds the faces of a cell (margin included)
+    // The first optic behind a point source sees every ray leave from ONE point O: with m = e2 x e1, E02 = (p0-O) x (p2-O),
+    // E10 = (p1-O) x (p0-O) the Moller-Trumbore quantities are f = d.m, u f = d.E02, v f = d.E10 -- three dot products per face.
+    const double* pt_rec;           // [n_first + 1][12] m, E02, E10, |m|^2 (+inf: degenerate), 2 spare; or null
+    // plane form of EVERY face (as plane_rec) for the second pass around the nearest point; [13]: how far outside (in
+    // barycentric units) a point must lie for the reference's area test (diff < 1e-10) to fail for sure
+    const XRT_G1 d4v* plane2_rec;   // [n_faces][16] or null (no second pass)
 };
 
 struct KOptic {
@@ -2490,6 +2504,9 @@ static size_t mesh_bytes(const xrt_mesh_t* m)
     b += al256(F * 24) + al256((n_first + 1) * 80) + al256((n_first + 1) * 128) + al256(F * sizeof(KFaceRec)) + al256(P * 32) + al256(P * 24);
     if (m->interpolate) b += 2 * al256(T * 3 * 4) + al256(T * 6 * 8) + al256(P * 2 * 8) + al256(4 * P * 8) + al256(8 * P * 8) + al256(P * 4);
     b += al256((2 * P + 1) * sizeof(KCellRec));                       // bucket grid: <= P buckets + <= P chained points
+    b += al256((64 * 64 + 1) * 4) + al256(n_first * 16 * 4 + 64) + al256(64 * 64 * 16);   // face grid of the first pass: cell starts, lists (<= 16 cells per face on average), cell slabs
+    b += al256((n_first + 1) * 96);                                   // point-source form of the first pass
+    if (Cn > 0) b += al256(F * 128);                                  // plane form of every face (second pass)
     return b;
 }
 static size_t meshes_bytes(const xrt_scene_t* sc)
@@ -3037,6 +3054,34 @@ static int upload_meshes(const xrt_scene_t* sc, char* ws, int n_runs, KScene* ks
             // plane form of the same faces for the classification pass: P - p0 = u e1 + v e2 (+ w n), n = e1 x e2,
             // u = (P - p0).U with U = (e2 x n) / (e1.(e2 x n)), v = (P - p0).V with V = (n x e1) / (e2.(n x e1))
             std::vector<double> pr((n_first + 1) * 16, 0.0);
+            auto plane_form = [](const double* p0, const double* e1, const double* e2, double* o) {
+                o[12] = HUGE_VAL;                                  // degenerate until shown otherwise
+                const double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+                const double a[3] = {e2[1] * n[2] - e2[2] * n[1], e2[2] * n[0] - e2[0] * n[2], e2[0] * n[1] - e2[1] * n[0]};   // e2 x n
+                const double b[3] = {n[1] * e1[2] - n[2] * e1[1], n[2] * e1[0] - n[0] * e1[2], n[0] * e1[1] - n[1] * e1[0]};   // n x e1
+                const double da = e1[0] * a[0] + e1[1] * a[1] + e1[2] * a[2], db = e2[0] * b[0] + e2[1] * b[1] + e2[2] * b[2];
+                const double nn = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+                bool ok = std::isfinite(nn) && nn > 0.0 && std::isfinite(da) && std::isfinite(db) && da != 0.0 && db != 0.0;
+                double U[3], V[3];
+                for (int c = 0; c < 3 && ok; c++) { U[c] = a[c] / da; V[c] = b[c] / db; ok = std::isfinite(U[c]) && std::isfinite(V[c]) && std::isfinite(p0[c]); }
+                if (!ok) return;
+                o[0] = n[0]; o[1] = n[1]; o[2] = n[2]; o[3] = n[0] * p0[0] + n[1] * p0[1] + n[2] * p0[2];
+                o[4] = U[0]; o[5] = U[1]; o[6] = U[2]; o[7] = -(U[0] * p0[0] + U[1] * p0[1] + U[2] * p0[2]);
+                o[8] = V[0]; o[9] = V[1]; o[10] = V[2]; o[11] = -(V[0] * p0[0] + V[1] * p0[1] + V[2] * p0[2]);
+                o[12] = nn;
+                if (!std::isfinite(o[3]) || !std::isfinite(o[7]) || !std::isfinite(o[11])) { for (int c = 0; c < 12; c++) o[c] = 0.0; o[12] = HUGE_VAL; }
+            };
+            if (Cn > 0) {
+                // every face for the second pass; [13] = 5e-10 / area (ten times the excess of the area sum the reference tolerates)
+                std::vector<double> p2(F * 16, 0.0);
+                for (size_t i = 0; i < F; i++) {
+                    plane_form(m->p0 + 3 * i, m->edge1 + 3 * i, m->edge2 + 3 * i, &p2[16 * i]);
+                    const double area = m->faces_area[i];
+                    p2[16 * i + 13] = (std::isfinite(area) && area > 0.0) ? 5e-10 / area : HUGE_VAL;
+                    if (!(p2[16 * i + 13] < 0.25)) p2[16 * i + 12] = HUGE_VAL;       // (tiny faces: always the exact test)
+                }
+                k.plane2_rec = (const XRT_G1 d4v*)put(p2.data(), p2.size() * 8);
+            } else k.plane2_rec = nullptr;
             for (size_t i = 0; i <= n_first; i++) {
                 double* o = &pr[16 * i];
                 o[12] = HUGE_VAL;                                  // degenerate until shown otherwise (the spare record too)
@@ -3058,6 +3103,115 @@ static int upload_meshes(const xrt_scene_t* sc, char* ws, int n_runs, KScene* ks
                 if (!std::isfinite(o[3]) || !std::isfinite(o[7]) || !std::isfinite(o[11])) { for (int c = 0; c < 12; c++) o[c] = 0.0; o[12] = HUGE_VAL; }
             }
             k.plane_rec = (const double*)put(pr.data(), pr.size() * 8);
+            // ---- point-source form (see KMesh.pt_rec): the mesh is the first optic behind a source without extent -------
+            k.pt_rec = nullptr;
+            {
+                const xrt_source_t& src = sc->source;
+                const bool point = e == 0 && (src.kind == XRT_SRC_GENERIC || src.kind == XRT_SRC_DIRECTED) && src.spatial_dist == XRT_SPATIAL_UNIFORM &&
+                                   src.size[0] == 0.0 && src.size[1] == 0.0 && src.size[2] == 0.0 && !env_on("XICSRT_NO_POINT_FORM");
+                if (point) {
+                    const xrt_optic_t& o = sc->optics[e];
+                    double Ol[3];           // the source point in the optic's frame (ray_to_local, optics/_TraceObject.py:146-148)
+                    for (int r = 0; r < 3; r++) {
+                        Ol[r] = 0.0;
+                        for (int c = 0; c < 3; c++) Ol[r] += o.orientation[3 * r + c] * (src.origin[c] - o.origin[c]);
+                    }
+                    std::vector<double> pt((n_first + 1) * 12, 0.0);
+                    for (size_t i = 0; i <= n_first; i++) {
+                        double* w = &pt[12 * i];
+                        w[9] = HUGE_VAL;
+                        if (i == n_first) break;
+                        const double *p0 = q0 + 3 * i, *e1 = q1 + 3 * i, *e2 = q2 + 3 * i;
+                        const double a[3] = {p0[0] - Ol[0], p0[1] - Ol[1], p0[2] - Ol[2]};
+                        const double b1[3] = {a[0] + e1[0], a[1] + e1[1], a[2] + e1[2]}, b2[3] = {a[0] + e2[0], a[1] + e2[1], a[2] + e2[2]};
+                        const double m[3] = {e2[1] * e1[2] - e2[2] * e1[1], e2[2] * e1[0] - e2[0] * e1[2], e2[0] * e1[1] - e2[1] * e1[0]};
+                        const double E02[3] = {a[1] * b2[2] - a[2] * b2[1], a[2] * b2[0] - a[0] * b2[2], a[0] * b2[1] - a[1] * b2[0]};
+                        const double E10[3] = {b1[1] * a[2] - b1[2] * a[1], b1[2] * a[0] - b1[0] * a[2], b1[0] * a[1] - b1[1] * a[0]};
+                        const double mm = m[0] * m[0] + m[1] * m[1] + m[2] * m[2];
+                        bool fin = std::isfinite(mm) && mm > 0.0;
+                        for (int c = 0; c < 3 && fin; c++) fin = std::isfinite(E02[c]) && std::isfinite(E10[c]);
+                        if (!fin) continue;
+                        for (int c = 0; c < 3; c++) { w[c] = m[c]; w[3 + c] = E02[c]; w[6 + c] = E10[c]; }
+                        w[9] = mm;
+                    }
+                    k.pt_rec = (const double*)put(pt.data(), pt.size() * 8);
+                }
+            }
+            // ---- x-y grid over these faces (see KMesh.fg_n) ----------------------------------------------------
+            k.fg_n = 0;
+            {
+                // (a ray's faces through the grid are gathered per lane, 128 bytes each; the plain walk reads every face once per
+                //  wave through scalar loads: measured on the 32 coarse faces of cfg5, the walk is 1.75 x faster)
+                bool ok = n_first > 128 && !env_on("XICSRT_NO_FACE_GRID");
+                double lo[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, hi[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL}, nb[3] = {0, 0, 0};
+                std::vector<double> fb(n_first * 6), fn(n_first * 3);
+                for (size_t i = 0; i < n_first && ok; i++) {
+                    const double *p0 = q0 + 3 * i, *e1 = q1 + 3 * i, *e2 = q2 + 3 * i;
+                    if (pr[16 * i + 12] == HUGE_VAL) { ok = false; break; }         // a degenerate face: every ray takes the whole walk
+                    for (int c = 0; c < 3; c++) {
+                        const double a = p0[c], b1 = p0[c] + e1[c], b2 = p0[c] + e2[c];
+                        double mn = a < b1 ? a : b1, mx = a > b1 ? a : b1;
+                        if (b2 < mn) mn = b2;
+                        if (b2 > mx) mx = b2;
+                        fb[6 * i + c] = mn; fb[6 * i + 3 + c] = mx;
+                        if (mn < lo[c]) lo[c] = mn;
+                        if (mx > hi[c]) hi[c] = mx;
+                    }
+                    const double nl = sqrt(pr[16 * i + 12]);
+                    for (int c = 0; c < 3; c++) { fn[3 * i + c] = pr[16 * i + c] / nl; }
+                }
+                if (ok) {
+                    // the cone of the face normals: orientation-free (a face and its flipped twin count alike)
+                    for (size_t i = 0; i < n_first; i++) {
+                        const double sgn = (fn[3 * i] * fn[0] + fn[3 * i + 1] * fn[1] + fn[3 * i + 2] * fn[2]) < 0.0 ? -1.0 : 1.0;
+                        for (int c = 0; c < 3; c++) nb[c] += sgn * fn[3 * i + c];
+                    }
+                    const double nl = sqrt(nb[0] * nb[0] + nb[1] * nb[1] + nb[2] * nb[2]);
+                    ok = std::isfinite(nl) && nl > 0.0;
+                    double cmin = 1.0;
+                    for (size_t i = 0; i < n_first && ok; i++) {
+                        const double c = fabs(fn[3 * i] * nb[0] + fn[3 * i + 1] * nb[1] + fn[3 * i + 2] * nb[2]) / nl;
+                        if (c < cmin) cmin = c;
+                    }
+                    const double ext = (hi[0] - lo[0]) > (hi[1] - lo[1]) ? (hi[0] - lo[0]) : (hi[1] - lo[1]);
+                    ok = ok && cmin > 0.5 && std::isfinite(ext) && ext > 0.0 && (hi[0] - lo[0]) > 0.0 && (hi[1] - lo[1]) > 0.0;
+                    if (ok) {
+                        // |d . nbar| / |d| >= sin(alpha) + 1e-3 keeps |d . n| / |d| >= ~1e-3 for every face normal n (alpha: the cone's half angle)
+                        k.fg_sin = sqrt(1.0 - cmin * cmin) + 1e-3;
+                        for (int c = 0; c < 3; c++) k.fg_nbar[c] = nb[c] / nl;
+                        const double margin = 1e-5 * ext;               // (classification tolerance 1e-7 in barycentric units, rounding: far inside)
+                        int g = (int)ceil(sqrt((double)n_first / 2.0));
+                        if (g < 1) g = 1;
+                        if (g > 64) g = 64;
+                        k.fg_n = g; k.fg_margin = margin;
+                        k.fg_x0 = lo[0] - margin; k.fg_y0 = lo[1] - margin;
+                        k.fg_ihx = (double)g / ((hi[0] - lo[0]) + 2.0 * margin); k.fg_ihy = (double)g / ((hi[1] - lo[1]) + 2.0 * margin);
+                        k.fg_zlo = lo[2] - margin; k.fg_zhi = hi[2] + margin;
+                        std::vector<std::vector<int32_t>> cells((size_t)g * g);
+                        auto cell_of = [&](double v, double v0, double ih) { int c = (int)floor((v - v0) * ih); return c < 0 ? 0 : (c > g - 1 ? g - 1 : c); };
+                        for (size_t i = 0; i < n_first; i++) {
+                            const int cx0 = cell_of(fb[6 * i] - margin, k.fg_x0, k.fg_ihx), cx1 = cell_of(fb[6 * i + 3] + margin, k.fg_x0, k.fg_ihx);
+                            const int cy0 = cell_of(fb[6 * i + 1] - margin, k.fg_y0, k.fg_ihy), cy1 = cell_of(fb[6 * i + 4] + margin, k.fg_y0, k.fg_ihy);
+                            for (int cy = cy0; cy <= cy1; cy++) for (int cx = cx0; cx <= cx1; cx++) cells[(size_t)cy * g + cx].push_back((int32_t)i);
+                        }
+                        std::vector<int32_t> start((size_t)g * g + 1), list;
+                        std::vector<double> zc((size_t)g * g * 2);
+                        for (size_t c = 0; c < (size_t)g * g; c++) {
+                            start[c] = (int32_t)list.size(); list.insert(list.end(), cells[c].begin(), cells[c].end());
+                            double zl = HUGE_VAL, zh = -HUGE_VAL;
+                            for (int32_t f : cells[c]) { if (fb[6 * f + 2] < zl) zl = fb[6 * f + 2]; if (fb[6 * f + 5] > zh) zh = fb[6 * f + 5]; }
+                            zc[2 * c] = zl - margin; zc[2 * c + 1] = zh + margin;
+                        }
+                        start[(size_t)g * g] = (int32_t)list.size();
+                        if (list.size() > n_first * 16) k.fg_n = 0;     // (more than the space set aside: a pathological mesh)
+                        else {
+                            k.fg_start = (gip)put(start.data(), start.size() * 4);
+                            k.fg_faces = (gip)put(list.empty() ? nullptr : list.data(), list.size() * 4);
+                            k.fg_zcell = (gdp)put(zc.data(), zc.size() * 8);
+                        }
+                    }
+                }
+            }
         }
         {   // per face what the second pass reads, per point its <= 8 faces
             std::vector<KFaceRec> fr(F);
@@ -3227,8 +3381,11 @@ static int launch_variant(const KScene* ks, const KArgs& a_in, int n_runs, size_
 {
     KArgs a = a_in;
     if (a.image_rep > 1u && a.images) a.images = a.images_rep;      // (the staged kernels add into the caller's bins)
-#ifdef XRT_DEV_ONLY_LEAN     // development builds: only the lean kernel is compiled (seconds instead of a minute)
-    if constexpr (HIST || VARIANT != 0) return fail(-3, "%s", "development build: lean kernels only");
+#ifdef XRT_DEV_ONLY_LEAN     // development builds: only the lean kernels (-DXRT_DEV_VARIANT=2: the mesh / local-frame ones) are compiled
+#ifndef XRT_DEV_VARIANT
+#define XRT_DEV_VARIANT 0
+#endif
+    if constexpr (HIST || VARIANT != XRT_DEV_VARIANT) return fail(-3, "%s", "development build: one kernel variant only");
     else {
 #endif
     auto kern = xrt_trace_kernel<HIST, VARIANT, SEG>;
