@@ -2565,7 +2565,7 @@ static int plasma_slots(const xrt_scene_t* sc, int n_runs)
 static size_t plasma_ws_bytes(const xrt_scene_t* sc, int n_runs)
 {
     if (!plasma_fused(sc)) return 0;
-    return al256((size_t)plasma_slots(sc, n_runs) * (plasma_slot_bytes(sc) + 8) + 256);
+    return al256((size_t)plasma_slots(sc, n_runs) * (plasma_slot_bytes(sc) + 16) + 512);
 }
 static size_t staged_bytes(const xrt_scene_t* sc, int n_runs)
 {
@@ -3450,6 +3450,7 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
         memset(&ps, 0, sizeof(ps));
         char* p = base;
         ps.n_src = reinterpret_cast<long long*>(p);                     p += al256((size_t)slots * 8);
+        ps.gauss0 = reinterpret_cast<double*>(p);                       p += al256((size_t)slots * 8);
         ps.btab = reinterpret_cast<double*>(p);                         p += (size_t)slots * al256(B * XRT_PB_ROWS * 8);
         ps.bpos = reinterpret_cast<long long*>(p);                      p += (size_t)slots * al256(B * XRT_PP_ROWS * 8);
         ps.ray_bundle = reinterpret_cast<uint32_t*>(p);                 p += (size_t)slots * al256(NN * 4);
@@ -3463,16 +3464,21 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
         a.run_counter = reinterpret_cast<uint32_t*>(ws);
         a.progress = env_on("XICSRT_NO_PRIORITY_FEEDBACK") ? nullptr : reinterpret_cast<unsigned long long*>(ws + 32);
         a.plasma.btab = ps.btab; a.plasma.bpos = ps.bpos; a.plasma.ray_bundle = ps.ray_bundle; a.plasma.wl = ps.wl;
-        a.plasma.dump = ps.dump; a.plasma.n_src = ps.n_src; a.plasma.dump_words = ps.dump_words;
+        a.plasma.dump = ps.dump; a.plasma.n_src = ps.n_src; a.plasma.dump_words = ps.dump_words; a.plasma.gauss0 = ps.gauss0;
         const bool ext = needs_ext(sc);
         const size_t lds = plan_queue(ks, 0, ext, false, &a);
         for (int base_run = 0; base_run < n_runs; base_run += slots) {
             const int nb = (n_runs - base_run) < slots ? (n_runs - base_run) : slots;
             ps.run_base = base_run; ps.n_runs = nb;
-            const size_t scout_lds = (sc->source.plasma && sc->source.plasma->voigt_gamma > 0.0) ? 4 * 2 * XRT_VOIGT_GRID * sizeof(double) : 0;
-            if (scout_lds)
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(xrt_plasma_scout_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scout_lds));
-            hipLaunchKernelGGL(xrt_plasma_scout_kernel, dim3((nb + 3) / 4), dim3(256), scout_lds, stream, device_scene(ws), streams, ps);
+            const bool voigt = sc->source.plasma && sc->source.plasma->voigt_gamma > 0.0;
+            const size_t scout_lds = voigt ? 4 * 2 * XRT_VOIGT_GRID * sizeof(double) : 0;
+            if (voigt) {
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(xrt_plasma_scout_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scout_lds));
+                hipLaunchKernelGGL((xrt_plasma_scout_kernel<true, true>), dim3((nb + 3) / 4), dim3(256), scout_lds, stream, device_scene(ws), streams, ps);
+            } else if (sc->source.plasma)
+                hipLaunchKernelGGL((xrt_plasma_scout_kernel<false, true>), dim3((nb + 3) / 4), dim3(256), 0, stream, device_scene(ws), streams, ps);
+            else
+                hipLaunchKernelGGL((xrt_plasma_scout_kernel<false, false>), dim3((nb + 3) / 4), dim3(256), 0, stream, device_scene(ws), streams, ps);
             HIP_TRY(hipGetLastError());
             a.streams = streams + base_run; a.heads = heads; a.n_runs = nb;
             HIP_TRY(hipMemsetAsync(ws, 0, 64, stream));
