@@ -43,10 +43,10 @@
 extern "C" {
 #endif
 
-#define XRT_ABI_VERSION 16
+#define XRT_ABI_VERSION 17
 
-#define XRT_MAX_OPTICS     16
-#define XRT_MAX_APERTURES  8
+#define XRT_MAX_OPTICS     64
+#define XRT_MAX_APERTURES  32
 
 /* ---- enumerations -------------------------------------------------------- */
 
@@ -106,7 +106,7 @@ typedef struct xrt_aperture {
 /* One XicsrtBundleFilterSightline (filters/_XicsrtBundleFilterSightline.py:31-56): a bundle is
  * kept when radius >= |l_0 - zaxis (zaxis . l_0)|, l_0 = origin - bundle centre; origin and zaxis
  * are the filter's config values as given (zaxis is NOT normalised by the reference). */
-#define XRT_MAX_BUNDLE_FILTERS 4
+#define XRT_MAX_BUNDLE_FILTERS 16
 typedef struct xrt_bundle_filter {
     double origin[3];
     double zaxis[3];

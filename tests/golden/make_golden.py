@@ -510,6 +510,40 @@ def build_cases():
     cfg2['sources']['source']['intensity'] = 60000
     add('Q_ten_counts', 'counts', cfg2)
 
+    # --- far beyond the sizes of the device structures' first form (16 optics, 8 apertures per optic, 4 filters): forty optics
+    #     -- 28 apertures in front of the crystal, one of them with twelve aperture shapes, the crystal, ten more on the reflected
+    #     beam, the detector -- and six sightline filters on an extended source
+    cfg40 = cfg_three(1500, dict(sph, rocking_fwhm=3e-3), history=True, seed=57,
+                      source=_source(1500, 8.0, xsize=0.004, ysize=0.004, zsize=0.002, filters=['f%d' % i for i in range(6)]))
+    cfg40['filters'] = {'f%d' % i: {'class_name': 'XicsrtBundleFilterSightline', 'origin': [0.0002 * (i - 2), -0.0001 * i, 0.8],
+                                    'zaxis': [0.0003 * (i - 3), 0.0002 * i, -1.0], 'radius': 0.0022 + 0.0002 * i} for i in range(6)}
+    optics = {}
+    for i in range(28):
+        z = 0.02 + 0.025 * i
+        aps = [{'shape': 'circle', 'size': [0.012 + 0.0042 * i]}]
+        if i == 9:
+            aps = [{'shape': 'circle', 'size': [0.06]}]
+            for j in range(11):
+                aps.append({'shape': ['circle', 'square', 'rectangle', 'ellipse'][j % 4], 'origin': [0.012 * (j - 5), 0.006 * ((j * 3) % 5 - 2)],
+                            'size': [[0.004], [0.007], [0.009, 0.005], [0.006, 0.004]][j % 4],
+                            'logic': ['not', 'not', 'or', 'not', 'xor', 'not', 'nor', 'xnor', 'nand', 'not', 'xor'][j]})
+        optics['ap%02d' % i] = {'class_name': 'XicsrtOpticAperture', 'origin': [0.0, 0.0, z], 'zaxis': [0.0, 0.0, -1.0],
+                                'xsize': 0.4, 'ysize': 0.4, 'aperture': aps}
+    optics['crystal'] = cfg40['optics']['crystal']
+    for i in range(10):
+        f = (i + 1) / 11.0
+        optics['out%02d' % i] = {'class_name': 'XicsrtOpticAperture', 'origin': (crystal_at + f * (det_at - crystal_at)).tolist(),
+                                 'zaxis': (-out_dir).tolist(), 'xsize': 0.5, 'ysize': 0.5,
+                                 'aperture': [{'shape': 'circle', 'size': [0.06 - 0.002 * i]}]}
+    optics['detector'] = cfg40['optics']['detector']
+    assert len(optics) == 40
+    cfg40['optics'] = optics
+    add('Q_forty_trace', 'trace', cfg40)
+    cfg40c = copy.deepcopy(cfg40)
+    cfg40c['general'].update(keep_history=False, number_of_iter=2, number_of_runs=2)
+    cfg40c['sources']['source']['intensity'] = 40000
+    add('Q_forty_counts', 'counts', cfg40c)
+
     # --- edge cases: empty and tiny ray arrays, tile boundaries of the device kernels (256 rays), nothing
     #     reaching the Bragg element, a single pixel, the largest scene the C ABI takes (16 optics) ------------
     for n in (0, 1, 2, 255, 256, 257):

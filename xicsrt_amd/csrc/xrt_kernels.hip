@@ -38,7 +38,7 @@
 
 #include "../../include/xicsrt_hip.h"
 
-#define XRT_DEV_MAX_OPTICS XRT_MAX_OPTICS      // (16) the scene lives in device memory: no kernel-argument limit
+#define XRT_DEV_MAX_OPTICS XRT_MAX_OPTICS      // (64) the scene lives in device memory: no kernel-argument limit
 #define XRT_TILE     256
 #define XRT_RING     1024u
 #define XRT_RMASK    1023u
@@ -2362,7 +2362,7 @@ extern "C" int xrt_scene_check(const xrt_scene_t* sc)
             return fail(-2, "%s", "a temperature profile with a natural linewidth needs voigt_gamma and the Weideman coefficients");
     }
     if (sc->n_optics < 0 || sc->n_optics > XRT_DEV_MAX_OPTICS)
-        return fail(-2, "%s", "device path supports at most 16 optics (XRT_MAX_OPTICS)");
+        return fail(-2, "%s", "device path supports at most 64 optics (XRT_MAX_OPTICS)");
     const xrt_source_t& s = sc->source;
     if (s.intensity < 0) return fail(-2, "%s", "negative intensity");
     if (s.spatial_dist != XRT_SPATIAL_UNIFORM && s.spatial_dist != XRT_SPATIAL_GAUSSIAN)
@@ -3354,7 +3354,8 @@ static int upload_scene(const KScene& ks, char* ws, hipStream_t stream)
     static_assert(sizeof(KScene) % 4 == 0, "scene size");
     const uint32_t* src = reinterpret_cast<const uint32_t*>(&ks);
     uint32_t* dst = reinterpret_cast<uint32_t*>(ws + ws_off_scene());
-    const int total = (int)(sizeof(KScene) / 4);
+    // (the source and the optics in use: 0.5 KB each of the 64 the structure has room for)
+    const int total = (int)((offsetof(KScene, opt) + sizeof(KOptic) * (size_t)(ks.n_optics > 0 ? ks.n_optics : 0) + 3) / 4);
     for (int o = 0; o < total; o += 512) {
         KBlob b;
         const int n = (total - o) < 512 ? (total - o) : 512;
@@ -3510,7 +3511,7 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
         a.streams = streams; a.heads = heads; a.n_runs = n_runs; a.n_src_heads = nh;
         a.run_counter = reinterpret_cast<uint32_t*>(ws);
         HIP_TRY(hipMemsetAsync(ws, 0, 64, stream));
-        const size_t lds = sizeof(double) * XRT_TILE_COMP * XRT_TILE + sizeof(uint32_t) * (2 * XRT_TILE + XRT_RING + 64);
+        const size_t lds = sizeof(double) * XRT_TILE_COMP * XRT_TILE + sizeof(uint32_t) * (2 * XRT_TILE + XRT_RING + 16 + 2 * (XRT_DEV_MAX_OPTICS + 2) + 16);
         int ti = -1;
         if (timing_on && timing_n < TIMING_MAX) {
             ti = timing_n++;

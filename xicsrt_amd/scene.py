@@ -20,10 +20,10 @@ import ctypes as C
 
 import numpy as np
 
-XRT_ABI_VERSION = 16
-XRT_MAX_BUNDLE_FILTERS = 4
-XRT_MAX_OPTICS = 16
-XRT_MAX_APERTURES = 8
+XRT_ABI_VERSION = 17
+XRT_MAX_BUNDLE_FILTERS = 16
+XRT_MAX_OPTICS = 64
+XRT_MAX_APERTURES = 32
 XRT_HIST_COMPONENTS = 8
 
 SRC_KIND = {'zaxis': 0, 'direction': 1, 'target': 2, 'plasma': 3, 'external': 4}
