@@ -2531,7 +2531,7 @@ static size_t staged_slot_bytes(const xrt_scene_t* sc)
     const size_t n = (size_t)(sc->source.intensity > 0 ? sc->source.intensity : 1);
     const size_t nb = (size_t)(sc->source.bundle_count > 0 ? sc->source.bundle_count : 0);
     const size_t voigt = (sc->source.plasma && sc->source.plasma->voigt_gamma > 0.0) ? 2 * XRT_VOIGT_GRID * sizeof(double) : 0;
-    return n * (XRT_ST_ARRAYS * sizeof(double) + 2 * sizeof(uint32_t)) + nb * XRT_ST_BUNDLE_ROWS * sizeof(double) + voigt + 16;
+    return n * (XRT_ST_ARRAYS * sizeof(double) + 3 * sizeof(uint32_t)) + nb * XRT_ST_BUNDLE_ROWS * sizeof(double) + voigt + 16;
 }
 // source and optics run as separate launches over batches of up to 4 x 256 run slots
 static int staged_slots(const xrt_scene_t* sc, int n_runs)
@@ -3501,7 +3501,8 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
         g.arr = reinterpret_cast<double*>(base);
         g.ids = reinterpret_cast<uint32_t*>(base + (size_t)slots * (size_t)N * XRT_ST_ARRAYS * sizeof(double));
         g.aux = g.ids + (size_t)slots * (size_t)N;
-        g.bundle_off = reinterpret_cast<double*>(base + (size_t)slots * (size_t)N * (XRT_ST_ARRAYS * sizeof(double) + 2 * sizeof(uint32_t)));
+        g.act = g.aux + (size_t)slots * (size_t)N;
+        g.bundle_off = reinterpret_cast<double*>(base + (size_t)slots * (size_t)N * (XRT_ST_ARRAYS * sizeof(double) + 3 * sizeof(uint32_t)));
         g.flags = reinterpret_cast<uint32_t*>(ws) + 16;        // status word in the 256-byte workspace header
         if (sc->source.plasma && sc->source.plasma->voigt_gamma > 0.0)      // behind the bundle tables and the per-slot counts
             g.voigt_tab = g.bundle_off + (size_t)slots * XRT_ST_BUNDLE_ROWS * (size_t)(sc->source.bundle_count > 0 ? sc->source.bundle_count : 0) + 2 * (size_t)slots;
