@@ -409,6 +409,11 @@ int xrt_selftest_div3(const double* num, const double* den, int64_t n, uint64_t*
 #define XRT_PATH_ONE_PASS     512u   /* segmented runs in one pass: Bragg candidates parked in HBM, stream offsets by look-back */
 uint32_t xrt_last_path(int32_t reset);
 
+/* np.random.shuffle(np.arange(n))[:m] of numpy's legacy generator (host only, no device): what
+ * _sort_raytrace draws to sample the lost rays (xicsrt/xicsrt_raytrace.py:264-266).  state in / out:
+ * np.random.get_state() layout (has_gauss / gauss pass through untouched).  out: m indices. */
+int xrt_legacy_shuffle_head(xrt_rng_state_t* state, int64_t n, int64_t m, int64_t* out);
+
 /* Diagnostic, host only: the MT19937 jump-ahead polynomial g(t) = t^J mod phi(t)
  * (phi = characteristic polynomial of the generator, degree 19937) that positions
  * the per-array generator heads: out624 receives 624 words, bit j of word j/32 = g_j,

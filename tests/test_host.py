@@ -370,3 +370,20 @@ def test_raytrace_raises_what_the_reference_raises_for_degenerate_run_settings(o
     cfg['general'].update(number_of_runs=2, number_of_iter=0)
     with pytest.raises(ZeroDivisionError):
         oracle_device.raytrace(cfg)
+
+
+@pytest.mark.parametrize('n,m,burn', [(200001, 1000, 0), (1000003, 10000, 17), (262144, 262144, 623), (300000, 0, 5), (2, 1, 0), (1, 1, 3),
+                                      (50000, 3125, 1), (50000, 3126, 1)])
+def test_legacy_shuffle_head_equals_numpy(n, m, burn):
+    """The library's walk through np.random.shuffle's draws (sample of the lost rays, _sort_raytrace) gives numpy's
+    own first m indices and leaves the generator where numpy leaves it, from any position of the state block."""
+    from xicsrt_amd import xicsrt_raytrace as xrt
+    a, b = np.random.RandomState(12345), np.random.RandomState(12345)
+    a.random_sample(burn); b.random_sample(burn)
+    a.standard_normal(1); b.standard_normal(1)          # a cached gauss value must pass through
+    index = np.arange(n)
+    a.shuffle(index)
+    got = xrt._shuffled_head(b, n, m, library_from=0)
+    assert np.array_equal(got, index[:m])
+    assert a.random_sample() == b.random_sample() and a.standard_normal() == b.standard_normal()
+

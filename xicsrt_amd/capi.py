@@ -16,7 +16,7 @@ EXPORTS = (
     'xrt_abi_version', 'xrt_last_error', 'xrt_sizeof_scene', 'xrt_scene_check',
     'xrt_device_count', 'xrt_workspace_bytes', 'xrt_trace', 'xrt_trace_history',
     'xrt_timing_begin', 'xrt_timing_end', 'xrt_mt_jump_poly', 'xrt_check', 'xrt_make_image', 'xrt_last_path',
-    'xrt_optic_intersect', 'xrt_optic_check_bounds', 'xrt_optic_interact', 'xrt_selftest_div3',
+    'xrt_optic_intersect', 'xrt_optic_check_bounds', 'xrt_optic_interact', 'xrt_selftest_div3', 'xrt_legacy_shuffle_head',
 )
 PATH_FUSED, PATH_STAGED, PATH_STAGE_SPLIT, PATH_JUMP, PATH_SEEK, PATH_SEGMENTED, PATH_GAUSS_PREPARED = 1, 2, 4, 8, 16, 32, 64
 PATH_PLASMA_SCOUT = 128
@@ -80,6 +80,8 @@ def lib():
     L.xrt_selftest_div3.restype = C.c_int
     L.xrt_selftest_div3.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     L.xrt_last_path.restype = C.c_uint32
+    L.xrt_legacy_shuffle_head.restype = C.c_int
+    L.xrt_legacy_shuffle_head.argtypes = [P(_scene.RngState), C.c_int64, C.c_int64, P(C.c_int64)]
     L.xrt_last_path.argtypes = [C.c_int32]
     L.xrt_timing_begin.restype = C.c_int
     L.xrt_timing_end.restype = C.c_int

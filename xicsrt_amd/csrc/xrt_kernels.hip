@@ -35,6 +35,9 @@
 #include <stdlib.h>
 #include <cmath>
 #include <vector>
+#include <unordered_map>
+#include <memory>
+#include <new>
 
 #include "../../include/xicsrt_hip.h"
 
@@ -4120,6 +4123,133 @@ extern "C" int xrt_selftest_div3(const double* num, const double* den, int64_t n
     hipLaunchKernelGGL(xrt_selftest_div3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_),
                        num, den, n, reinterpret_cast<unsigned long long*>(bad));
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---- np.random.shuffle(np.arange(n))[:m] of numpy's legacy generator, on the host (xicsrt_raytrace.py:264-266: the
+// reference shuffles the indices of ALL lost rays to keep `history_max_lost` of them).  The draws are sequential by
+// contract -- Fisher-Yates from the back, random_interval(i) by masked rejection on 32-bit words
+// (numpy/random/_legacy: legacy_random_interval via mt19937 next_uint32) -- but they do not depend on the array, so they
+// are made 64 at a time and the cells they name are prefetched before the swaps: the walk is bound by the generator, not by
+// cache misses.  `state`: key[624], pos, has_gauss, gauss in and out.
+extern "C" int xrt_legacy_shuffle_head(xrt_rng_state_t* state, int64_t n, int64_t m, int64_t* out)
+{
+    if (!state || (m > 0 && !out) || n < 0 || m < 0) return fail(-1, "%s", "bad argument");
+    if (state->pos < 0 || state->pos > 624) return fail(-2, "%s", "generator position out of range");
+    if (n > 0xffffffffll) return fail(-3, "%s", "more than 2^32 - 1 indices");
+    if (m > n) m = n;
+    uint32_t* mt = state->key;
+    int pos = state->pos;
+    auto next32 = [&]() -> uint32_t {
+        if (pos >= 624) {
+            int k;
+            for (k = 0; k < 624 - 397; k++) { const uint32_t y = (mt[k] & 0x80000000u) | (mt[k + 1] & 0x7fffffffu); mt[k] = mt[k + 397] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u); }
+            for (; k < 623; k++) { const uint32_t y = (mt[k] & 0x80000000u) | (mt[k + 1] & 0x7fffffffu); mt[k] = mt[k + (397 - 624)] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u); }
+            const uint32_t y = (mt[623] & 0x80000000u) | (mt[0] & 0x7fffffffu);
+            mt[623] = mt[396] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            pos = 0;
+        }
+        uint32_t y = mt[pos++];
+        y ^= (y >> 11); y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= (y >> 18);
+        return y;
+    };
+    if (n > 1 && m * 16 <= n) {
+        // few indices wanted: keep the draws (streamed, 4 bytes each) and follow only the m wanted cells backwards in
+        // time -- cell k of the result holds what stood at sigma_{n-1}(...sigma_2(sigma_1(k))) at the start, sigma_i the
+        // swap (i j_i) -- with a bitmap of the followed cells (n/8 bytes, cache resident) in front of the map.
+        std::unique_ptr<uint32_t[]> J(new (std::nothrow) uint32_t[(size_t)n]);     // not zeroed: every cell from 1 up is written
+        if (!J) return fail(-4, "%s", "out of host memory");
+        {   // the draws: whole blocks of 624 tempered words (loops the compiler vectorises), consumed with the mask of
+            // the current power-of-two span of i held constant and the rejection folded into the index step
+            uint32_t buf[624];
+            int have = 0, used = 0;
+            auto refill = [&]() {
+                if (pos >= 624) {
+                    auto tw = [](uint32_t u, uint32_t l, uint32_t far) -> uint32_t {
+                        const uint32_t y = (u & 0x80000000u) | (l & 0x7fffffffu);
+                        return far ^ (y >> 1) ^ ((0u - (y & 1u)) & 0x9908b0dfu);
+                    };
+                    for (int k = 0; k < 227; k++) mt[k] = tw(mt[k], mt[k + 1], mt[k + 397]);
+                    for (int k = 227; k < 454; k++) mt[k] = tw(mt[k], mt[k + 1], mt[k - 227]);
+                    for (int k = 454; k < 623; k++) mt[k] = tw(mt[k], mt[k + 1], mt[k - 227]);
+                    mt[623] = tw(mt[623], mt[0], mt[396]);
+                    pos = 0;
+                }
+                have = 624 - pos; used = 0;
+                for (int k = 0; k < have; k++) {
+                    uint32_t y = mt[pos + k];
+                    y ^= (y >> 11); y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= (y >> 18);
+                    buf[k] = y;
+                }
+            };
+            int64_t i = n - 1;
+            while (i >= 1) {
+                const int64_t lo = (int64_t)1 << (63 - __builtin_clzll((unsigned long long)i));   // span [lo, 2 lo)
+                const uint32_t mask = (uint32_t)(2 * lo - 1);
+                while (i >= lo) {
+                    if (used == have) { pos += used; refill(); }
+                    int q = used;
+                    int64_t ii = i;
+                    for (; q < have && ii >= lo; q++) {
+                        const uint32_t v = buf[q] & mask;
+                        J[(size_t)ii] = v;
+                        ii -= (v <= (uint32_t)ii);
+                    }
+                    used = q; i = ii;
+                }
+            }
+            pos += used;
+        }
+        std::vector<uint64_t> bits((size_t)(n + 63) / 64, 0);
+        std::unordered_map<uint32_t, uint32_t> cell;           // followed position -> index of the result
+        cell.reserve((size_t)m * 2 + 16);
+        for (int64_t k = 0; k < m; k++) { cell[(uint32_t)k] = (uint32_t)k; bits[(size_t)k >> 6] |= 1ull << (k & 63); }
+        auto move = [&](uint32_t from, uint32_t to) {
+            auto it = cell.find(from);
+            const uint32_t k = it->second;
+            cell.erase(it);
+            cell[to] = k;
+            bits[from >> 6] &= ~(1ull << (from & 63));
+            bits[to >> 6] |= 1ull << (to & 63);
+        };
+        for (int64_t i = 1; i < m; i++) {                        // both cells of a swap can be followed ones
+            const uint32_t j = J[(size_t)i];
+            if (j == (uint32_t)i) continue;
+            if ((bits[j >> 6] >> (j & 63)) & 1u) std::swap(cell[(uint32_t)i], cell[j]);
+            else move((uint32_t)i, j);
+        }
+        for (int64_t i = (m > 1 ? m : 1); i < n; i++) {          // cell i itself is never a followed one from here on
+            const uint32_t j = J[(size_t)i];
+            if ((bits[j >> 6] >> (j & 63)) & 1u) move(j, (uint32_t)i);
+        }
+        for (const auto& kv : cell) out[kv.second] = (int64_t)kv.first;
+        state->pos = pos;
+        return 0;
+    }
+    std::vector<uint32_t> x((size_t)n);
+    for (int64_t i = 0; i < n; i++) x[(size_t)i] = (uint32_t)i;
+    const int B = 64;
+    uint32_t js[B];
+    int64_t i = n - 1;
+    while (i >= 1) {
+        const int cnt = (int)(i < B ? i : B);       // iterations i, i-1, ..., i-cnt+1 (all >= 1)
+        for (int q = 0; q < cnt; q++) {
+            const uint32_t mx = (uint32_t)(i - q);
+            uint32_t mask = mx;
+            mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+            uint32_t v;
+            do { v = next32() & mask; } while (v > mx);
+            js[q] = v;
+            __builtin_prefetch(&x[v], 1, 0);
+        }
+        for (int q = 0; q < cnt; q++) {
+            const size_t a = (size_t)(i - q), b = (size_t)js[q];
+            const uint32_t t = x[a]; x[a] = x[b]; x[b] = t;
+        }
+        i -= cnt;
+    }
+    for (int64_t q = 0; q < m; q++) out[q] = (int64_t)x[(size_t)q];
+    state->pos = pos;
     return 0;
 }
 

@@ -362,7 +362,20 @@ def _empty_output(config):
 
 def _history_from_device(names, rays, mask, optics=None):
     """
-    Per-element ray dictionaries in original ray order from the device snapshot.
+    Per-element ray dictionaries in original ray order from the device snapshot `rays` [element, 8, ray],
+    `mask` [element, ray] (see _history_from_parts).
+    """
+    # (copies: with a single ray the transposed view is already contiguous and would alias `rays`)
+    origin = np.array(rays[:, 0:3, :].transpose(0, 2, 1), order='C', copy=True)
+    direction = np.array(rays[:, 3:6, :].transpose(0, 2, 1), order='C', copy=True)
+    return _history_from_parts(names, origin, direction, rays[:, 6, :].copy(), rays[0, 7, :].copy(),
+                               np.array(mask, copy=True), optics)
+
+
+def _history_from_parts(names, origin, direction, wavelength, weight, mask, optics=None):
+    """
+    Per-element ray dictionaries from origin / direction [element, ray, 3], wavelength / mask [element, ray] and
+    the source's weight [ray]; the arrays are taken over (updated in place, the dictionaries hold views of them).
     Rays that died at an element carry the intersection point they died at
     (or NaN), later elements see NaN origins and the unchanged direction, as
     the reference's masked NumPy updates leave them (optics/_ShapeObject.py:76-79,
@@ -372,31 +385,21 @@ def _history_from_device(names, rays, mask, optics=None):
     orientation matrix is not exactly orthonormal; that round trip is replayed here.
     """
     history = {}
-    n = mask.shape[1]
-    prev_dir = None
-    prev_wl = None
-    prev_mask = None
     for e, name in enumerate(names):
-        # (copies: with a single ray the transposed view is already contiguous and would alias `rays`)
-        origin = np.array(rays[e, 0:3, :].T, order='C', copy=True)
-        direction = np.array(rays[e, 3:6, :].T, order='C', copy=True)
-        wavelength = rays[e, 6, :].copy()
-        m = mask[e].copy()
         if e > 0:
-            dead_before = ~prev_mask
-            origin[dead_before] = np.nan
-            direction[dead_before] = prev_dir[dead_before]
-            wavelength[dead_before] = prev_wl[dead_before]
-            obj = optics[e - 1] if optics is not None and e - 1 < len(optics) else None
-            if obj is not None and obj.param.get('trace_local') and dead_before.any():
-                d = np.ascontiguousarray(direction[dead_before])
-                direction[dead_before] = obj.vector_to_external(obj.vector_to_local(d))
-        history[name] = RayArray({'origin': origin, 'direction': direction,
-                                  'wavelength': wavelength, 'mask': m})
+            dead_before = ~mask[e - 1]
+            if dead_before.any():
+                origin[e][dead_before] = np.nan
+                direction[e][dead_before] = direction[e - 1][dead_before]
+                wavelength[e][dead_before] = wavelength[e - 1][dead_before]
+                obj = optics[e - 1] if optics is not None and e - 1 < len(optics) else None
+                if obj is not None and obj.param.get('trace_local'):
+                    d = np.ascontiguousarray(direction[e][dead_before])
+                    direction[e][dead_before] = obj.vector_to_external(obj.vector_to_local(d))
+        history[name] = RayArray({'origin': origin[e], 'direction': direction[e],
+                                  'wavelength': wavelength[e], 'mask': mask[e]})
         if e == 0:
-            history[name]['weight'] = rays[e, 7, :].copy()
-        prev_dir, prev_wl, prev_mask = direction, wavelength, m
-    assert n == len(prev_mask)
+            history[name]['weight'] = weight
     return history
 
 
@@ -417,6 +420,27 @@ def _sort_history(history, rng, max_lost):
     return found, lost
 
 
+def _shuffled_head(rng, n, m, library_from=500000):
+    """np.arange(n) shuffled by `rng` (numpy's legacy RandomState), first m entries; the generator ends where
+    rng.shuffle leaves it.  The reference shuffles the indices of all lost rays to keep history_max_lost of them
+    (xicsrt_raytrace.py:264-266); the draws are sequential by contract, and for millions of rays numpy's shuffle is the
+    longest step of the call (1e7 indices: 0.24 s).  The library makes the same draws and follows only the m wanted cells."""
+    if n < library_from:
+        index = np.arange(n)
+        rng.shuffle(index)
+        return index[:m]
+    from . import capi
+    st = rng.get_state()
+    state = xscene.RngState()
+    C.memmove(state.key, np.ascontiguousarray(st[1], dtype=np.uint32).ctypes.data, 624 * 4)
+    state.pos, state.has_gauss, state.gauss = int(st[2]), int(st[3]), float(st[4])
+    out = np.empty(m, dtype=np.int64)
+    capi.check(capi.lib().xrt_legacy_shuffle_head(C.byref(state), n, m, out.ctypes.data_as(C.POINTER(C.c_int64))),
+               'xrt_legacy_shuffle_head')
+    rng.set_state(('MT19937', np.ctypeslib.as_array(state.key).copy(), int(state.pos), int(st[3]), float(st[4])))
+    return out
+
+
 def _sorted_history_from_device(elements, device, d_rays, d_mask, rng, max_lost):
     """
     _sort_raytrace (xicsrt_raytrace.py:229-278) without moving every ray to the host: the masks come
@@ -426,23 +450,24 @@ def _sorted_history_from_device(elements, device, d_rays, d_mask, rng, max_lost)
     _history_from_device + _sort_history on the full arrays.
     """
     t = device.torch
-    mask_all = d_mask.cpu().numpy().astype(bool)
-    n = mask_all.shape[1]
+    n = d_mask.shape[1]
     if device.flat.struct.source.kind == xscene.SRC_KIND['plasma']:
-        n = int(mask_all[0].sum())        # plasma sources: the ray count is drawn, the arrays hold the capacity
-    mask_h = mask_all[:, :n]
-    last = mask_h[-1]
-    w_found = np.flatnonzero(last)
-    w_lost = np.flatnonzero(np.invert(last))
-    max_lost = min(max_lost, len(w_lost))
-    index_lost = np.arange(len(w_lost))
-    rng.shuffle(index_lost)
-    w_lost = w_lost[index_lost[:max_lost]]
-    sel = np.concatenate([w_found, w_lost]).astype(np.int64)
-    d_sel = t.from_numpy(sel).to(d_rays.device)
-    rays_sel = d_rays.index_select(2, d_sel).cpu().numpy()
-    history = _history_from_device(elements.names, rays_sel, mask_h[:, sel], elements.optics)
-    nf = len(w_found)
+        n = int((d_mask[0] != 0).sum())   # plasma sources: the ray count is drawn, the arrays hold the capacity
+    last = d_mask[-1, :n] != 0
+    d_found = t.nonzero(last).flatten()                   # ascending, as np.flatnonzero
+    d_lost = t.nonzero(~last).flatten()
+    max_lost = min(max_lost, d_lost.numel())
+    head = _shuffled_head(rng, d_lost.numel(), max_lost)
+    d_sel = t.cat([d_found, d_lost[t.from_numpy(np.ascontiguousarray(head, dtype=np.int64)).to(d_lost.device)]])
+    rays_sel = d_rays.index_select(2, d_sel)
+    # laid out on the device as the dictionaries want them, so the host arrays are views of what comes over
+    history = _history_from_parts(elements.names,
+                                  rays_sel[:, 0:3, :].transpose(1, 2).contiguous().cpu().numpy(),
+                                  rays_sel[:, 3:6, :].transpose(1, 2).contiguous().cpu().numpy(),
+                                  rays_sel[:, 6, :].contiguous().cpu().numpy(),
+                                  rays_sel[0, 7, :].contiguous().cpu().numpy(),
+                                  (d_mask.index_select(1, d_sel) != 0).cpu().numpy(), elements.optics)
+    nf = d_found.numel()
     found = {key: {k: v[:nf] for k, v in history[key].items()} for key in history}
     lost = {key: {k: v[nf:] for k, v in history[key].items()} for key in history}
     return found, lost
@@ -485,6 +510,19 @@ def combine_raytrace(input_list, keep_images=True, components=None):
 
     if len(input_list[0]['found']['history']) > 0:
         for group in ('found', 'lost'):
+            if num == 1:
+                # one entry: its arrays are the result (the other ray fields zero, as below)
+                for key_opt in key_opt_list:
+                    h = input_list[0][group]['history'][key_opt]
+                    rays = RayArray()
+                    rays.zeros(0)
+                    for name in list(rays):
+                        if name not in _RAY_KEYS:
+                            rays[name] = np.zeros((len(h['mask']),) + rays[name].shape[1:], dtype=rays[name].dtype)
+                    for key_ray in _RAY_KEYS:
+                        rays[key_ray] = np.ascontiguousarray(h[key_ray])
+                    output[group]['history'][key_opt] = rays
+                continue
             total = sum(len(entry[group]['history'][key_opt_last]['mask']) for entry in input_list)
             for key_opt in key_opt_list:
                 rays = RayArray()
