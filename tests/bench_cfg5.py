@@ -9,7 +9,7 @@ runs = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 rays = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000
 rep = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 lib = capi.lib()
-for tag in ('flat', 'interp', 'norefine', '81_coarse17'):
+for tag in os.environ.get('CFG5_TAGS', 'flat,interp,norefine,81_coarse17').split(','):
     cfg, _ = helpers.load_golden('E_cfg5_mesh_%s_1e5' % tag if tag in ('flat', 'interp') else 'E_mesh_%s_counts' % tag)
     cfg = copy.deepcopy(cfg)
     cfg['general'].update(number_of_runs=runs, number_of_iter=1, keep_history=False)

@@ -22,6 +22,7 @@ PATH_FUSED, PATH_STAGED, PATH_STAGE_SPLIT, PATH_JUMP, PATH_SEEK, PATH_SEGMENTED,
 PATH_PLASMA_SCOUT = 128
 PATH_LDS_BINS = 256
 PATH_ONE_PASS = 512
+PATH_MESH_SPLIT = 1024
 
 _lib = None
 

@@ -122,6 +122,7 @@ struct KMesh {               // device pointers, see xrt_mesh_t
     const XRT_G1 d4v* face_rec;     // [n_faces] KFaceRec, read as four 32-byte vectors
     gip point_faces;                // [n_points][8] the faces around a point, -1 where the reference's mask is False
     gip ct_simplices, ct_neighbors;
+    const XRT_G1 d4v* ct_srec;      // [n_simplices] 96 bytes: the three vertices, the edge vectors e12, e23, e31, the neighbour weights g (ct_shared)
     gdp ct_transform, ct_points, ct_values, ct_grad;
     gip ct_vertex_simplex;
     // x-y bucket grid over the points for the exact nearest-point search (built by the library)
@@ -143,6 +144,11 @@ struct KMesh {               // device pointers, see xrt_mesh_t
     // plane form of EVERY face (as plane_rec) for the second pass around the nearest point; [13]: how far outside (in
     // barycentric units) a point must lie for the reference's area test (diff < 1e-10) to fail for sure
     const XRT_G1 d4v* plane2_rec;   // [n_faces][16] or null (no second pass)
+    // A small mesh in LDS (xrt_mesh_rest_lds_kernel; lds_bytes = 0: does not fit / not applicable): the cells above,
+    // per point its <= 8 faces and per face the cells that hold its three vertices (p0, p1, p2), as 16-bit numbers
+    const uint16_t* lds_pf;         // [n_points][8], 0xffff: none
+    const uint16_t* lds_fv;         // [n_faces][4] (the fourth is padding)
+    int32_t n_cells, lds_bytes;
 };
 
 struct KOptic {
@@ -170,7 +176,8 @@ struct KOptic {
     double  scr_binv, scr_dmax, scr_ptail;      // 1 / (2 sigma^2), validity radius in d, bound on p outside it
     // screen for rays with their own wavelength: inc - bragg from sin(inc - bragg) = c sqrt(1-s^2) - s sqrt(1-c^2)
     double  scr2_tail, inv_two_d;               // bound on p for |sin(inc - bragg)| >= 0.01; 1 / (2 d)
-    int32_t scr2_ok, pad3;
+    int32_t scr2_ok;
+    int32_t mesh_lds_bytes;             // host side: KMesh.lds_bytes of `mesh` (which launch finishes a split mesh intersection)
 };
 
 struct KScene {
@@ -1106,6 +1113,11 @@ struct KArgs {
     uint32_t* cand_aux;                 // [n_runs][cand_cap] hit face (variant 2)
     int64_t   cand_cap;
     uint32_t* unit_flag;                // [n_runs][n_seg * n_sub], zero before the launch
+    // SEG == 3 / 4 (the phases of SEG == 2 as launches of their own around xrt_mesh_rest_kernel, a mesh crystal): that
+    // kernel finishes the intersection of every parked ray and leaves per ray the hit point, the normal and in cand_aux
+    // XRT_CAND_DEAD for a ray that is out; per 64 rays and per unit the number left alive (= Bragg draws)
+    uint32_t* batch_alive;              // [n_runs][cand_cap / 64]
+    uint32_t* unit_alive;               // [n_runs][n_seg * n_sub], zero before the launch
     unsigned long long* dbg;            // development: [units][8] wall-clock stamps of a unit's phases (null: none)
     // Pixel bins of the fused kernel: `images` may point to image_rep replicas, image_stride bins apart, which the library
     // sums into the caller's bins behind the last launch.  Scattered 8-byte atomics execute at the memory side, and all
@@ -1124,6 +1136,8 @@ struct KArgs {
     KPlasmaRays plasma;                 // XRT_SRC_PLASMA: what xrt_plasma_scout_kernel left per run slot (run index = slot)
 };
 
+#define XRT_CAND_DEAD 0xfffffffeu
+#define XRT_MESH_LDS_MAX (150u * 1024u)     // tables of xrt_mesh_rest_lds_kernel: one 1024-thread workgroup per CU
 #ifndef XRT_WAVES_PER_EU
 #define XRT_WAVES_PER_EU 4
 #endif
@@ -1159,13 +1173,20 @@ __device__ __forceinline__ const KScene* scene_fresh(const KScene* p)
 //   SEG == 1 (two passes; candidate buffers beyond the workspace budget): a first launch (mode 1) only counts every
 //     unit's candidates and the second (mode 2) starts each unit at the position the counts of the earlier units give.
 template <bool HIST, int VARIANT, int SEG>
-__global__ __launch_bounds__(XRT_TILE, (VARIANT == 2 ? 2 : XRT_WAVES_PER_EU))
+__global__ __launch_bounds__(XRT_TILE, ((VARIANT == 2 && SEG < 3) ? 2 : XRT_WAVES_PER_EU))
 void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
 {
     constexpr bool FULL = VARIANT == 1 || VARIANT == 2;
     constexpr bool EXT = VARIANT == 2;
     constexpr bool LEANWL = VARIANT == 3;       // the lean geometry with a prepared wavelength per ray
     constexpr bool LBINS = VARIANT == 4;        // the lean geometry without a Bragg test, pixel bins pre-aggregated in LDS
+    // SEG >= 2: the candidates of the Bragg element are parked in HBM.  3 / 4 (a mesh crystal, variant 2 only): the two phases
+    // as launches of their own -- 3: rays up to the first pass over the mesh's faces, parked with the face; then
+    // xrt_mesh_rest_kernel finishes the intersection of every parked ray (a thread per ray, at the occupancy its own
+    // registers allow); 4: Bragg test and the elements behind over what is left.  Neither compiles any of the mesh code
+    // but the first pass: four workgroups per CU instead of two.
+    constexpr bool PH_A = SEG != 4, PH_B = SEG != 3, SPLIT = SEG >= 3;
+    static_assert(!SPLIT || (VARIANT == 2 && !HIST), "split phases: mesh variant without histories only");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     // One circular structure-of-arrays buffer of XRT_QCAP ray records serves as
     //  (a) the FIFO queue of rays waiting for the Bragg test (filled tile by tile in ray
@@ -1247,7 +1268,7 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
     // interpolation, bounds -- on the dense lanes of a Bragg batch, in ray order, just in front of their Bragg test.
     bool mesh_pre = false;
     // (SEG == 2 counts a unit's candidates in its first phase: the whole intersection runs there)
-    if constexpr (EXT && SEG != 2) mesh_pre = be >= 0 && SC.opt[be].shape == XRT_SHAPE_MESH;
+    if constexpr (EXT && SEG != 2) mesh_pre = be >= 0 && SC.opt[be].shape == XRT_SHAPE_MESH;      // (SEG >= 3: always, by the host's choice of route)
 
     double wl_run = 0.0;        // the wavelength of every ray when it is not part of the records
     auto q_store = [&](uint32_t i, const V3& o, const V3& d, double wl, uint32_t id) __attribute__((always_inline)) {
@@ -1267,12 +1288,14 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
     double* cbase = nullptr;
     size_t crun = 0;                // first ray-index / face word of the run
     // (blocks of 256 records, component-major inside a block: what a batch reads lies in one 12 - 14 KB stretch)
-    const int q_ncomp = q_has_wl ? 7 : 6;
+    // (split phases: + the surface normal at the hit point, components 6 - 8, which xrt_mesh_rest_kernel leaves)
+    const int q_wlc = SPLIT ? 9 : 6;
+    const int q_ncomp = q_wlc + (q_has_wl ? 1 : 0);
     auto cand_store = [&](int64_t i, const V3& o, const V3& d, double wl, uint32_t id, int aux) __attribute__((always_inline)) {
         double* c = cbase + (i >> 8) * (int64_t)(q_ncomp * 256) + (i & 255);
         c[0 * 256] = o.x; c[1 * 256] = o.y; c[2 * 256] = o.z;
         c[3 * 256] = d.x; c[4 * 256] = d.y; c[5 * 256] = d.z;
-        if (q_has_wl) c[6 * 256] = wl;
+        if (q_has_wl) c[q_wlc * 256] = wl;
         if (HIST) args.cand_id[crun + i] = id;
         if (EXT) args.cand_aux[crun + i] = (uint32_t)aux;
     };
@@ -1280,9 +1303,15 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
         const double* c = cbase + (i >> 8) * (int64_t)(q_ncomp * 256) + (i & 255);
         o.x = c[0 * 256]; o.y = c[1 * 256]; o.z = c[2 * 256];
         d.x = c[3 * 256]; d.y = c[4 * 256]; d.z = c[5 * 256];
-        wl = q_has_wl ? c[6 * 256] : wl_run;
+        wl = q_has_wl ? c[q_wlc * 256] : wl_run;
         id = HIST ? args.cand_id[crun + i] : 0u;
         aux = EXT ? (int)args.cand_aux[crun + i] : 0;
+    };
+    auto cand_normal = [&](int64_t i) __attribute__((always_inline)) -> V3 {
+        const double* c = cbase + (i >> 8) * (int64_t)(q_ncomp * 256) + (i & 255);
+        V3 n;
+        n.x = c[6 * 256]; n.y = c[7 * 256]; n.z = c[8 * 256];
+        return n;
     };
 
     for (;;) {
@@ -1299,7 +1328,7 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
         if (run >= (uint32_t)args.n_runs) break;
         const bool counting = SEG == 1 && args.mode == 1;
         const bool last_unit = !SEG || uidx + 1u == upr;
-        if constexpr (SEG == 2) {
+        if constexpr (SEG >= 2) {
             crun = (size_t)run * (size_t)args.cand_cap;
             cbase = args.cand + crun * (size_t)q_ncomp;
         }
@@ -1322,7 +1351,7 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
         // words then occupy one half of every ring ([0,512) or [512,1024), alternating), all heads use the
         // same LDS offsets (the ring number goes into the instruction's immediate offset), and the next
         // tile's half is generated in three fixed chunks of 171, 171 and 170 words (<= 227 are independent).
-        {
+        if constexpr (PH_A) {
             uint32_t havail[6];
             int h = 0;
 #pragma unroll
@@ -1393,7 +1422,7 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
         };
         // SEG == 2 with a Bragg element: the head is opened behind the unit's first phase, when the units in front have
         // published their candidate counts
-        const bool deferred = SEG == 2 && be >= 0;
+        const bool deferred = SEG >= 2 && be >= 0;
         if (!deferred) {
             // SEG == 1, second launch, with a Bragg optic: the candidates of the earlier units of this run, summed by the
             // whole workgroup.  Without a Bragg optic only the run's last unit needs the stream (to store the run's new head).
@@ -1481,7 +1510,7 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
         };
         stamp(0);
         if constexpr (SEG == 2) __builtin_amdgcn_s_setprio(2);       // (first phase: above the units in their second phase)
-        if (SEG) heads_skip((ray_lo < ray_hi) ? (int64_t)sub * (args.sub_len / XRT_TILE) : 0);
+        if constexpr (SEG != 0 && PH_A) heads_skip((ray_lo < ray_hi) ? (int64_t)sub * (args.sub_len / XRT_TILE) : 0);
         stamp(1);
 
         // A point source (no spatial array in use: every offset is -0 + 0 u = 0) has one origin per run;
@@ -1534,10 +1563,15 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
                                 X = ray.o;
                                 alive = hit;
                             } else {
-                            if (is_mesh) {
-                                const MeshHit h = mesh_hit(op.mesh, ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z);
-                                hit = h.hit != 0; X.x = h.x; X.y = h.y; X.z = h.z; aux = h.aux;
-                            } else hit = intersect_point<FULL>(op, ray, X, false, pre0);
+                            bool whole_mesh = false;
+                            if constexpr (!SPLIT) {        // (split phases: the Bragg element is the scene's only mesh)
+                                if (is_mesh) {
+                                    const MeshHit h = mesh_hit(op.mesh, ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z);
+                                    hit = h.hit != 0; X.x = h.x; X.y = h.y; X.z = h.z; aux = h.aux;
+                                    whole_mesh = true;
+                                }
+                            }
+                            if (!whole_mesh) hit = intersect_point<FULL>(op, ray, X, false, pre0);
                             alive = hit && check_bounds<FULL>(op, X);
                             }
                             if (HIST && !alive && !counting) {
@@ -1555,7 +1589,9 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
                         if (alive) {
                             ray.o = X;
                             if (op.interact != XRT_INTERACT_NONE) {
-                                V3 nrm = is_mesh ? mesh_normal(op.mesh, X.x, X.y, aux) : surface_normal<FULL>(op, X);
+                                V3 nrm;
+                                if constexpr (!SPLIT) nrm = is_mesh ? mesh_normal(op.mesh, X.x, X.y, aux) : surface_normal<FULL>(op, X);
+                                else nrm = surface_normal<FULL>(op, X);
                                 double dt = dot_e(ray.d, nrm);
                                 ray.d.x = ray.d.x - 2.0 * (dt * nrm.x);
                                 ray.d.y = ray.d.y - 2.0 * (dt * nrm.y);
@@ -1806,7 +1842,7 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
         };
 
         // ---- tiles of 256 rays in original order ----------------------------
-        for (int64_t i0 = ray_lo; i0 < ray_hi; i0 += XRT_TILE) {
+        for (int64_t i0 = ray_lo; PH_A && i0 < ray_hi; i0 += XRT_TILE) {
             const int64_t left = ray_hi - i0;
             const uint32_t n_tile = left < XRT_TILE ? (uint32_t)left : (uint32_t)XRT_TILE;
             scl = scene_fresh(scene_g);
@@ -1903,7 +1939,7 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
                 uint32_t n_a;
                 mt_step();
                 uint32_t rank = wg_rank<true>(alive, wave_tot, slot, tid, n_a, rot_here);
-                if constexpr (SEG == 2) {
+                if constexpr (SEG >= 2) {
                     if (alive) cand_store(ray_lo + (int64_t)(n_candidates + rank), X, ray.d, ray.wl, id, aux);
                     n_candidates += n_a;
                 } else if constexpr (EXT) {
@@ -1919,7 +1955,7 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
             }
 
             // ---- Bragg test, a batch (128 or 256) of queued rays at a time ------------------
-            if constexpr (SEG != 2) {
+            if constexpr (SEG < 2) {
                 const bool last_tile = (i0 + XRT_TILE >= ray_hi);
                 while (be >= 0 && (qcount >= bbatch || (last_tile && qcount > 0u))) {
                     const uint32_t nb = qcount < bbatch ? qcount : bbatch;
@@ -1932,26 +1968,35 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
         // ---- SEG == 2: the unit's parked candidates.  Publish their number, wait for the numbers of the units in front
         // (handed out earlier by the dispenser: under way or done, and waiting for nothing behind them), open the stream
         // head at the position their sum gives, then Bragg test + the elements behind it, a batch at a time.
-        if constexpr (SEG == 2) {
+        if constexpr (SEG >= 2) {
             if (be >= 0) {
                 unsigned long long* acc = reinterpret_cast<unsigned long long*>(bcast + 2);
                 stamp(2);
                 __builtin_amdgcn_s_setprio(0);
-                __syncthreads();                                    // (the candidates of the last tile are written: global stores complete)
-                if (tid == 0) {
-                    __hip_atomic_store(&args.unit_flag[unit], n_candidates + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    *acc = 0ULL;
+                if constexpr (PH_A) {
+                    __syncthreads();                                // (the candidates of the last tile are written: global stores complete)
+                    if (tid == 0) __hip_atomic_store(&args.unit_flag[unit], n_candidates + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+              if constexpr (PH_B) {
+                // (split phases: the launches in front are complete -- the unit's candidates as its first phase counted them,
+                //  the Bragg draws of a unit = the candidates xrt_mesh_rest_kernel left alive)
+                if constexpr (SEG == 4) n_candidates = uni32(args.unit_flag[unit]) - 1u;
+                uint32_t n_unit_draws = n_candidates;
+                if constexpr (SEG == 4) n_unit_draws = uni32(args.unit_alive[unit]);
+                if (tid == 0) *acc = 0ULL;
                 lds_barrier();
                 unsigned long long part = 0;
                 for (uint32_t q = (uint32_t)tid; q < uidx; q += XRT_TILE) {
-                    const uint32_t* f = &args.unit_flag[(size_t)run * upr + q];
-                    uint32_t v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    while (v == 0u) {
-                        __builtin_amdgcn_s_sleep(8);
-                        v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if constexpr (SEG == 4) part += (unsigned long long)args.unit_alive[(size_t)run * upr + q];
+                    else {
+                        const uint32_t* f = &args.unit_flag[(size_t)run * upr + q];
+                        uint32_t v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        while (v == 0u) {
+                            __builtin_amdgcn_s_sleep(8);
+                            v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        part += (unsigned long long)(v - 1u);
                     }
-                    part += (unsigned long long)(v - 1u);
                 }
                 if (part) atomicAdd(acc, part);
                 lds_barrier();
@@ -2011,7 +2056,16 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
                         wave_fence();
                     }
                     lds_barrier();
-                    if (kb < ke) ring_to(first + 128ull * (uint64_t)(kb + 1u));
+                    // the wave's first Bragg uniform: one per candidate in front (split phases: per candidate left alive in front)
+                    uint64_t upos = first + 128ull * (uint64_t)kb;
+                    if constexpr (SEG == 4) {
+                        const uint32_t* ba = args.batch_alive + ((crun + (size_t)ray_lo) >> 6);
+                        uint32_t in_front = 0;
+                        for (uint32_t q = (uint32_t)lane; q < kb; q += 64u) in_front += ba[q];
+                        for (int o = 32; o > 0; o >>= 1) in_front += __shfl_xor(in_front, o);
+                        upos = first + 2ull * (uint64_t)uni32(in_front);
+                    }
+                    if (kb < ke) ring_to(upos + 128ull);
                     uint32_t qn = 0;            // records in this wave's queue
                     scl = scene_fresh(scene_g);
                     const bool img_b = (SC.opt[be].flags & XRT_F_IMAGE) && args.images;
@@ -2058,11 +2112,15 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
                                         rb.o = to_local(op.R, sub3(rb.o, ld3(op.origin)));
                                         rb.d = to_local(op.R, rb.d);
                                     }
-                                    bool hit;
-                                    if (is_mesh) {
-                                        const MeshHit h = mesh_hit(op.mesh, rb.o.x, rb.o.y, rb.o.z, rb.d.x, rb.d.y, rb.d.z);
-                                        hit = h.hit != 0; Xb.x = h.x; Xb.y = h.y; Xb.z = h.z; auxb = h.aux;
-                                    } else hit = intersect_point<FULL>(op, rb, Xb, false, pre0);
+                                    bool hit = false, whole_mesh = false;
+                                    if constexpr (!SPLIT) {        // (split phases: the Bragg element is the scene's only mesh)
+                                        if (is_mesh) {
+                                            const MeshHit h = mesh_hit(op.mesh, rb.o.x, rb.o.y, rb.o.z, rb.d.x, rb.d.y, rb.d.z);
+                                            hit = h.hit != 0; Xb.x = h.x; Xb.y = h.y; Xb.z = h.z; auxb = h.aux;
+                                            whole_mesh = true;
+                                        }
+                                    }
+                                    if (!whole_mesh) hit = intersect_point<FULL>(op, rb, Xb, false, pre0);
                                     alive_b = hit && check_bounds<FULL>(op, Xb);
                                     if (HIST && !alive_b) {
                                         V3 xo = Xb, dd = rb.d;
@@ -2077,7 +2135,9 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
                                     if (alive_b) {
                                         rb.o = Xb;
                                         if (op.interact != XRT_INTERACT_NONE) {
-                                            V3 nrm = is_mesh ? mesh_normal(op.mesh, Xb.x, Xb.y, auxb) : surface_normal<FULL>(op, Xb);
+                                            V3 nrm;
+                                            if constexpr (!SPLIT) nrm = is_mesh ? mesh_normal(op.mesh, Xb.x, Xb.y, auxb) : surface_normal<FULL>(op, Xb);
+                                            else nrm = surface_normal<FULL>(op, Xb);
                                             double dt = dot_e(rb.d, nrm);
                                             rb.d.x = rb.d.x - 2.0 * (dt * nrm.x);
                                             rb.d.y = rb.d.y - 2.0 * (dt * nrm.y);
@@ -2123,28 +2183,42 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
                     };
 
                     // ---- this wave's batches: candidates 64 k .. 64 k + 63, k = wave, wave + 4, ...
-                    V3 pf_x, pf_d;
+                    V3 pf_x, pf_d, pf_n;
                     double pf_wl = wl_run;
                     uint32_t pf_id = 0;
                     int pf_aux = 0;
-                    pf_x.x = pf_x.y = pf_x.z = 0.0; pf_d = pf_x;
-                    if (kb < ke && 64u * kb + (uint32_t)lane < n_candidates)
+                    pf_x.x = pf_x.y = pf_x.z = 0.0; pf_d = pf_x; pf_n = pf_x;
+                    if (kb < ke && 64u * kb + (uint32_t)lane < n_candidates) {
                         cand_load(ray_lo + (int64_t)(64u * kb + (uint32_t)lane), pf_x, pf_d, pf_wl, pf_id, pf_aux);
+                        if constexpr (SPLIT) pf_n = cand_normal(ray_lo + (int64_t)(64u * kb + (uint32_t)lane));
+                    }
                     for (uint32_t k = kb; k < ke; k++) {
                         const uint32_t c = 64u * k + (uint32_t)lane;
-                        const bool have = c < n_candidates;
+                        bool have = c < n_candidates;
                         bool alive = false;
                         Ray ray;
                         V3 X = pf_x;
                         uint32_t id = pf_id;
                         int baux = pf_aux;
                         ray.o = X; ray.d = pf_d; ray.wl = pf_wl;
+                        const V3 nrm_rec = pf_n;
+                        // which of the batch's uniforms is this candidate's (split phases: the candidates left alive draw, in ray order)
+                        uint32_t draw = (uint32_t)lane, n_draws = 64u;
+                        if constexpr (SEG == 4) {
+                            have = have && (uint32_t)baux != XRT_CAND_DEAD;
+                            const unsigned long long hb = __ballot(have);
+                            draw = __builtin_amdgcn_mbcnt_hi((uint32_t)(hb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hb, 0u));
+                            n_draws = (uint32_t)__popcll(hb);
+                        }
 #ifndef XRT_ABL_NOLOAD
-                        if (k + 1u < ke && c + 64u < n_candidates) cand_load(ray_lo + (int64_t)(c + 64u), pf_x, pf_d, pf_wl, pf_id, pf_aux);   // the wave's next batch
+                        if (k + 1u < ke && c + 64u < n_candidates) {       // the wave's next batch
+                            cand_load(ray_lo + (int64_t)(c + 64u), pf_x, pf_d, pf_wl, pf_id, pf_aux);
+                            if constexpr (SPLIT) pf_n = cand_normal(ray_lo + (int64_t)(c + 64u));
+                        }
 #endif
-                        // this batch's uniforms: words first + 128 k .. + 128 (np.random.uniform(0,1,n_live), optics/_InteractCrystal.py:189)
+                        // this batch's uniforms: words upos .. upos + 2 n_draws (np.random.uniform(0,1,n_live), optics/_InteractCrystal.py:189)
 #ifndef XRT_ABL_NORING
-                        ring_to(first + 128ull * (uint64_t)(k + 1u));
+                        ring_to(upos + 128ull);
 #endif
                         scl = scene_fresh(scene_g);
                         const KOptic& op = SC.opt[be];
@@ -2153,13 +2227,16 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
 #else
                         if (have) {
 #endif
-                            const uint32_t n = (uint32_t)first + 128u * k + 2u * (uint32_t)lane;
+                            const uint32_t n = (uint32_t)upos + 2u * draw;
                             const double test = 0.0 + (1.0 - 0.0) * mt_double(wring[n & XRT_RMASK], wring[(n + 1u) & XRT_RMASK]);
                             if constexpr (EXT) {
                                 const bool local = (op.flags & XRT_F_TRACE_LOCAL) != 0;
                                 V3 nrm;
-                                if (op.shape == XRT_SHAPE_MESH) nrm = mesh_normal(op.mesh, X.x, X.y, baux);
-                                else nrm = surface_normal<FULL>(op, X);
+                                if constexpr (SPLIT) nrm = nrm_rec;
+                                else {
+                                    if (op.shape == XRT_SHAPE_MESH) nrm = mesh_normal(op.mesh, X.x, X.y, baux);
+                                    else nrm = surface_normal<FULL>(op, X);
+                                }
                                 alive = bragg_accept(op, ray, nrm, test, wl_shared, bragg_shared);
                                 if (HIST && !alive) {
                                     V3 xo = X, dd = ray.d;
@@ -2203,6 +2280,7 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
 #ifdef XRT_ABL_NOSURV
                         alive = alive && (id == 0xffffffffu);
 #endif
+                        upos += 2ull * (uint64_t)n_draws;
                         // the reflected rays join the wave's queue
                         const unsigned long long sb = __ballot(alive);
                         if (sb != 0ULL) {
@@ -2226,7 +2304,7 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
                     // ---- the run's last unit hands the stream on: position behind the run's last Bragg uniform, 512 words
                     // generated ahead (the canonical form; a few more may be in the ring, which holds the 624 words in front all the same)
                     if (last_unit) {
-                        const uint64_t end = first + 2ull * (uint64_t)n_candidates;
+                        const uint64_t end = first + 2ull * (uint64_t)n_unit_draws;
                         if (wave == 0) ring_to(end + (uint64_t)XRT_AHEAD);
                         lds_barrier();
                         const uint32_t* r0 = reinterpret_cast<const uint32_t*>(lds_raw);
@@ -2235,6 +2313,7 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
                     }
                 }
                 stamp(4);
+              }
             }
         }
 
@@ -2287,6 +2366,195 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
             }
         }
         lds_barrier();
+    }
+}
+
+// Between the two phases of a split one-pass launch (xrt_trace_kernel<false, 2, 3> and <.., 4>): the rest of
+// ShapeMesh.intersect (optics/_ShapeMesh.py:289-432 behind the first pass: hit point of the face, nearest fine point, the
+// <= 8 faces around it, interpolation), the bounds and the normal for every ray the first phase parked, a thread per ray.
+// Nothing here depends on a neighbour or on a stream: the grid is (unit, block of 256 of its rays), the registers are
+// those of the mesh code alone (CT = false: a mesh without interpolation, no Clough-Tocher code).
+template <bool CT>
+__global__ __launch_bounds__(XRT_TILE)
+void xrt_mesh_rest_kernel(const KScene* __restrict__ scene_g, const KArgs args, int be, uint32_t blocks_per_unit)
+{
+    const KScene* scl = scene_fresh(scene_g);
+    const uint32_t unit = blockIdx.x / blocks_per_unit, blk = blockIdx.x - unit * blocks_per_unit;
+    const uint32_t n_unit = uni32(args.unit_flag[unit]) - 1u;
+    if (256u * blk >= n_unit) return;
+    const uint32_t upr = (uint32_t)args.n_seg * (uint32_t)args.n_sub;
+    const uint32_t run = unit / upr, uidx = unit - run * upr;
+    const uint32_t seg = uidx / (uint32_t)args.n_sub, sub = uidx - seg * (uint32_t)args.n_sub;
+    const int64_t N = SRC.n_rays;
+    const int64_t seg_lo = (int64_t)seg * args.seg_len;
+    const int64_t seg_hi = (seg_lo + args.seg_len < N) ? seg_lo + args.seg_len : N;
+    int64_t ray_lo = seg_lo + (int64_t)sub * args.sub_len;
+    if (ray_lo > seg_hi) ray_lo = seg_hi;
+    const bool q_has_wl = !(SRC.wavelength_dist == XRT_WL_CONST && !SRC.has_velocity);
+    const int q_ncomp = 9 + (q_has_wl ? 1 : 0);
+    const size_t crun = (size_t)run * (size_t)args.cand_cap;
+    const int64_t i = ray_lo + (int64_t)(256u * blk + (uint32_t)threadIdx.x);
+    double* c = args.cand + crun * (size_t)q_ncomp + (i >> 8) * (int64_t)(q_ncomp * 256) + (i & 255);
+    const bool have = 256u * blk + (uint32_t)threadIdx.x < n_unit;
+    const KOptic& op = SC.opt[be];
+    bool alive = false;
+    if (have) {
+        const int face = (int)args.cand_aux[crun + (size_t)i];
+        CtShared G;
+        int idx = -1;
+        MeshHit h = mesh_rest_impl<false>(op.mesh, c[0 * 256], c[1 * 256], c[2 * 256], c[3 * 256], c[4 * 256], c[5 * 256], face, &idx);
+        if constexpr (CT) { if (h.hit != 0) mesh_rest_ct(op.mesh, idx, h, G); }
+        V3 X;
+        X.x = h.x; X.y = h.y; X.z = h.z;
+        alive = (h.hit != 0) && check_bounds<true>(op, X);
+        if (alive) {
+            V3 nrm;
+            if constexpr (CT) nrm = mesh_normal_kept(op.mesh, G, h.aux);
+            else nrm = mesh_normal_impl<false>(op.mesh, X.x, X.y, h.aux);
+            c[0 * 256] = X.x; c[1 * 256] = X.y; c[2 * 256] = X.z;
+            c[6 * 256] = nrm.x; c[7 * 256] = nrm.y; c[8 * 256] = nrm.z;
+        } else args.cand_aux[crun + (size_t)i] = XRT_CAND_DEAD;
+    }
+    const unsigned long long ab = __ballot(alive);
+    if ((threadIdx.x & 63u) == 0u) {
+        const uint32_t n = (uint32_t)__popcll(ab);
+        args.batch_alive[((crun + (size_t)ray_lo) >> 6) + 4u * blk + (threadIdx.x >> 6)] = n;
+        if (n) atomicAdd(&args.unit_alive[unit], n);
+    }
+}
+
+// The same for a mesh whose tables fit the LDS (KMesh.lds_bytes > 0; see mesh_rest_lds): one 1024-thread workgroup per
+// CU keeps the tables and takes blocks of 1024 parked rays round robin.
+#define XRT_MESH_LDS_THREADS 1024
+// DEFER (an interpolated mesh): only up to the hit face; the hit point and the nearest point's index (in the slot of the
+// normal's first component) are left for xrt_mesh_ct_kernel, which interpolates, checks the bounds and counts.
+template <bool DEFER>
+__global__ __launch_bounds__(XRT_MESH_LDS_THREADS)
+void xrt_mesh_rest_lds_kernel(const KScene* __restrict__ scene_g, const KArgs args, int be, uint32_t blocks_per_unit, uint32_t n_units)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const KScene* scl = scene_fresh(scene_g);
+    const KOptic& op = SC.opt[be];
+    const KMesh* Mp = op.mesh;
+    MeshRef M = *(const XRT_C4 KMesh*)uniform_u64((uint64_t)Mp);
+    const int tid = threadIdx.x;
+    // tables: cells | point faces | face vertices | faces of the first pass
+    const uint32_t nc = (uint32_t)M.n_cells, np = (uint32_t)M.n_points, nf = (uint32_t)M.n_faces, n1 = (uint32_t)M.n_first + 1u;
+    d4v* l_cells = reinterpret_cast<d4v*>(lds_raw);
+    uint32_t* l_pf = reinterpret_cast<uint32_t*>(l_cells + nc);                // [np][4] words
+    uint32_t* l_fv = l_pf + 4u * np;                                           // [nf][2] words
+    double* l_first = reinterpret_cast<double*>(l_fv + 2u * nf);
+    {
+        const XRT_G1 d4v* g = M.cells;
+        for (uint32_t i = (uint32_t)tid; i < nc; i += XRT_MESH_LDS_THREADS) l_cells[i] = g[i];
+        const XRT_G1 uint32_t* gp = (const XRT_G1 uint32_t*)(uint64_t)M.lds_pf;
+        for (uint32_t i = (uint32_t)tid; i < 4u * np; i += XRT_MESH_LDS_THREADS) l_pf[i] = gp[i];
+        const XRT_G1 uint32_t* gf = (const XRT_G1 uint32_t*)(uint64_t)M.lds_fv;
+        for (uint32_t i = (uint32_t)tid; i < 2u * nf; i += XRT_MESH_LDS_THREADS) l_fv[i] = gf[i];
+        const XRT_G1 double* g1 = (const XRT_G1 double*)(uint64_t)M.first_rec;
+        for (uint32_t i = (uint32_t)tid; i < 10u * n1; i += XRT_MESH_LDS_THREADS) l_first[i] = g1[i];
+    }
+    __syncthreads();
+    MeshLds L;
+    L.cells = (lcell)l_cells;
+    L.pf = (const XRT_LDS3 uint16_t*)l_pf;
+    L.fv = (const XRT_LDS3 uint16_t*)l_fv;
+    L.first = (const XRT_LDS3 double*)l_first;
+    const int64_t N = SRC.n_rays;
+    const bool q_has_wl = !(SRC.wavelength_dist == XRT_WL_CONST && !SRC.has_velocity);
+    const int q_ncomp = 9 + (q_has_wl ? 1 : 0);
+    const uint32_t upr = (uint32_t)args.n_seg * (uint32_t)args.n_sub;
+    const uint64_t items = (uint64_t)n_units * blocks_per_unit;             // (unit, block of 1024 rays)
+    for (uint64_t it = blockIdx.x; it < items; it += gridDim.x) {
+        const uint32_t unit = (uint32_t)(it / blocks_per_unit), blk = (uint32_t)(it - (uint64_t)unit * blocks_per_unit);
+        const uint32_t n_unit = uni32(args.unit_flag[unit]) - 1u;
+        if (1024u * blk >= n_unit) continue;
+        const uint32_t run = unit / upr, uidx = unit - run * upr;
+        const uint32_t seg = uidx / (uint32_t)args.n_sub, sub = uidx - seg * (uint32_t)args.n_sub;
+        const int64_t seg_lo = (int64_t)seg * args.seg_len;
+        const int64_t seg_hi = (seg_lo + args.seg_len < N) ? seg_lo + args.seg_len : N;
+        int64_t ray_lo = seg_lo + (int64_t)sub * args.sub_len;
+        if (ray_lo > seg_hi) ray_lo = seg_hi;
+        const size_t crun = (size_t)run * (size_t)args.cand_cap;
+        const uint32_t k = 1024u * blk + (uint32_t)tid;
+        const int64_t i = ray_lo + (int64_t)k;
+        double* c = args.cand + crun * (size_t)q_ncomp + (i >> 8) * (int64_t)(q_ncomp * 256) + (i & 255);
+        const bool have = k < n_unit;
+        bool alive = false;
+        if (have) {
+            const int face = (int)args.cand_aux[crun + (size_t)i];
+            int idx;
+            const MeshHit h = mesh_rest_lds(Mp, L, c[0 * 256], c[1 * 256], c[2 * 256], c[3 * 256], c[4 * 256], c[5 * 256], face, idx);
+            V3 X;
+            X.x = h.x; X.y = h.y; X.z = h.z;
+            if constexpr (DEFER) {
+                if (h.hit != 0) {
+                    c[0 * 256] = X.x; c[1 * 256] = X.y; c[2 * 256] = X.z;
+                    c[6 * 256] = __hiloint2double(0, idx);
+                } else args.cand_aux[crun + (size_t)i] = XRT_CAND_DEAD;
+            } else {
+                alive = (h.hit != 0) && check_bounds<true>(op, X);
+                if (alive) {
+                    const V3 nrm = mesh_normal_impl<false>(Mp, X.x, X.y, h.aux);
+                    c[0 * 256] = X.x; c[1 * 256] = X.y; c[2 * 256] = X.z;
+                    c[6 * 256] = nrm.x; c[7 * 256] = nrm.y; c[8 * 256] = nrm.z;
+                } else args.cand_aux[crun + (size_t)i] = XRT_CAND_DEAD;
+            }
+        }
+        if constexpr (DEFER) continue;
+        const unsigned long long ab = __ballot(alive);
+        if ((tid & 63) == 0 && 64u * (k >> 6) < ((n_unit + 63u) & ~63u)) {
+            const uint32_t n = (uint32_t)__popcll(ab);
+            args.batch_alive[((crun + (size_t)ray_lo) >> 6) + (k >> 6)] = n;
+            if (n) atomicAdd(&args.unit_alive[unit], n);
+        }
+    }
+}
+
+// Behind xrt_mesh_rest_lds_kernel<true>: the interpolated height and normal (SciPy CloughTocher2DInterpolator, see
+// xrt_mesh.inc), the bounds and the counts for every parked ray that hit a face, a thread per ray.
+__global__ __launch_bounds__(XRT_TILE)
+void xrt_mesh_ct_kernel(const KScene* __restrict__ scene_g, const KArgs args, int be, uint32_t blocks_per_unit)
+{
+    const KScene* scl = scene_fresh(scene_g);
+    const uint32_t unit = blockIdx.x / blocks_per_unit, blk = blockIdx.x - unit * blocks_per_unit;
+    const uint32_t n_unit = uni32(args.unit_flag[unit]) - 1u;
+    if (256u * blk >= n_unit) return;
+    const uint32_t upr = (uint32_t)args.n_seg * (uint32_t)args.n_sub;
+    const uint32_t run = unit / upr, uidx = unit - run * upr;
+    const uint32_t seg = uidx / (uint32_t)args.n_sub, sub = uidx - seg * (uint32_t)args.n_sub;
+    const int64_t N = SRC.n_rays;
+    const int64_t seg_lo = (int64_t)seg * args.seg_len;
+    const int64_t seg_hi = (seg_lo + args.seg_len < N) ? seg_lo + args.seg_len : N;
+    int64_t ray_lo = seg_lo + (int64_t)sub * args.sub_len;
+    if (ray_lo > seg_hi) ray_lo = seg_hi;
+    const bool q_has_wl = !(SRC.wavelength_dist == XRT_WL_CONST && !SRC.has_velocity);
+    const int q_ncomp = 9 + (q_has_wl ? 1 : 0);
+    const size_t crun = (size_t)run * (size_t)args.cand_cap;
+    const int64_t i = ray_lo + (int64_t)(256u * blk + (uint32_t)threadIdx.x);
+    double* c = args.cand + crun * (size_t)q_ncomp + (i >> 8) * (int64_t)(q_ncomp * 256) + (i & 255);
+    const bool have = 256u * blk + (uint32_t)threadIdx.x < n_unit && args.cand_aux[crun + (size_t)i] != XRT_CAND_DEAD;
+    const KOptic& op = SC.opt[be];
+    bool alive = false;
+    if (have) {
+        MeshHit h;
+        h.x = c[0 * 256]; h.y = c[1 * 256]; h.z = c[2 * 256]; h.aux = 0; h.hit = 1;
+        CtShared G;
+        mesh_rest_ct(op.mesh, __double2loint(c[6 * 256]), h, G);
+        V3 X;
+        X.x = h.x; X.y = h.y; X.z = h.z;
+        alive = check_bounds<true>(op, X);
+        if (alive) {
+            const V3 nrm = mesh_normal_kept(op.mesh, G, h.aux);
+            c[2 * 256] = X.z;
+            c[6 * 256] = nrm.x; c[7 * 256] = nrm.y; c[8 * 256] = nrm.z;
+        } else args.cand_aux[crun + (size_t)i] = XRT_CAND_DEAD;
+    }
+    const unsigned long long ab = __ballot(alive);
+    if ((threadIdx.x & 63u) == 0u) {
+        const uint32_t n = (uint32_t)__popcll(ab);
+        args.batch_alive[((crun + (size_t)ray_lo) >> 6) + 4u * blk + (threadIdx.x >> 6)] = n;
+        if (n) atomicAdd(&args.unit_alive[unit], n);
     }
 }
 
@@ -2505,11 +2773,12 @@ static size_t mesh_bytes(const xrt_mesh_t* m)
     const size_t P = (size_t)m->n_points, F = (size_t)m->n_faces, Cn = (size_t)m->n_coarse_faces, T = (size_t)m->n_simplices;
     const size_t n_first = Cn > 0 ? Cn : F;
     b += al256(F * 24) + al256((n_first + 1) * 80) + al256((n_first + 1) * 128) + al256(F * sizeof(KFaceRec)) + al256(P * 32) + al256(P * 24);
-    if (m->interpolate) b += 2 * al256(T * 3 * 4) + al256(T * 6 * 8) + al256(P * 2 * 8) + al256(4 * P * 8) + al256(8 * P * 8) + al256(P * 4);
+    if (m->interpolate) b += 2 * al256(T * 3 * 4) + al256(T * 6 * 8) + al256(P * 2 * 8) + al256(4 * P * 8) + al256(8 * P * 8) + al256(P * 4) + al256(T * 96);
     b += al256((2 * P + 1) * sizeof(KCellRec));                       // bucket grid: <= P buckets + <= P chained points
     b += al256((64 * 64 + 1) * 4) + al256(n_first * 16 * 4 + 64) + al256(64 * 64 * 16);   // face grid of the first pass: cell starts, lists (<= 16 cells per face on average), cell slabs
     b += al256((n_first + 1) * 96);                                   // point-source form of the first pass
     if (Cn > 0) b += al256(F * 128);                                  // plane form of every face (second pass)
+    b += al256(P * 16) + al256(F * 8);                                // 16-bit tables of the LDS form
     return b;
 }
 static size_t meshes_bytes(const xrt_scene_t* sc)
@@ -2588,6 +2857,7 @@ struct SegPlan {
     int n_sub; int64_t sub_len;     // seg_len = n_sub * sub_len
     int n_chunk_heads; int64_t chunk_words;
     int n_gchunks; int64_t gpairs;  // Gaussian wavelengths: chunks of the candidate stream, candidate pairs per chunk
+    bool mesh_split;                // a mesh crystal: first phase, xrt_mesh_rest_kernel, second phase as launches of their own
 };
 static int count_heads(const xrt_scene_t* sc);
 static bool needs_ext(const xrt_scene_t* sc);
@@ -2597,6 +2867,17 @@ static int bragg_element(const xrt_scene_t* sc)
     for (int e = 0; e < sc->n_optics; e++)
         if (sc->optics[e].interact == XRT_INTERACT_CRYSTAL && (sc->optics[e].flags & XRT_F_CHECK_BRAGG)) be = e;
     return be;
+}
+// A mesh crystal that makes the Bragg test, and the scene's only mesh: the one-pass route in three launches (see
+// xrt_trace_kernel, SEG == 3 / 4), whole runs included when there are many
+static bool mesh_split_ok(const xrt_scene_t* sc)
+{
+    if (env_on("XICSRT_NO_MESH_SPLIT") || env_on("XICSRT_SEG_TWO_PASS") || getenv("XICSRT_NO_JUMP")) return false;
+    const int be = bragg_element(sc);
+    if (be < 0 || sc->optics[be].shape != XRT_SHAPE_MESH || sc->source.kind == XRT_SRC_PLASMA) return false;
+    for (int e = 0; e < sc->n_optics; e++)
+        if (e != be && sc->optics[e].shape == XRT_SHAPE_MESH) return false;
+    return sc->source.intensity >= 4096;
 }
 // Cost model of a plan in microseconds (measured on MI355X).  The jump kernel takes a run's jobs in
 // groups of eight: 20 us for a run's stretch + 255 us of one CU per group, spread evenly over the CUs.  A walk costs
@@ -2615,8 +2896,9 @@ static double jump_cost_us(int n_runs, int jobs_per_run)
 }
 static SegPlan plan_segments(const xrt_scene_t* sc, int n_runs)
 {
-    SegPlan p = {1, 0, 1, 0, 0, 0, 0, 0};
+    SegPlan p = {1, 0, 1, 0, 0, 0, 0, 0, false};
     if (needs_staged(sc)) return p;
+    const bool msplit = mesh_split_ok(sc);
     const int64_t N = sc->source.intensity;
     const bool gauss = gauss_prepared(sc->source);
     int want = 0, want_sub = 0;                 // units per run, parts per segment (0: by the cost model)
@@ -2625,7 +2907,7 @@ static SegPlan plan_segments(const xrt_scene_t* sc, int n_runs)
     else if (n_runs < 256) {
         // one round of units, all resident together and of one size: as many as workgroups fit on the chip (a second
         // round for a few units more would double the time), four per CU (two for the mesh / local-frame variant)
-        int target = 256 * (needs_ext(sc) ? 2 : 4);
+        int target = 256 * ((needs_ext(sc) && !msplit) ? 2 : 4);
         if (const char* t = getenv("XICSRT_TARGET_UNITS")) target = atoi(t) > 0 ? atoi(t) : target;
         want = target / n_runs;
     }
@@ -2685,7 +2967,8 @@ static SegPlan plan_segments(const xrt_scene_t* sc, int n_runs)
         n = (N + len - 1) / len;
         if (n * sub <= 1 || n > 4096) { n = 1; len = 0; sub = 1; sublen = 0; }
     } else sub = 1;
-    if (n == 1 && sub == 1 && !gauss) { p.gpairs = 0; p.n_gchunks = 0; return p; }
+    if (n == 1 && sub == 1 && !gauss && !msplit) { p.gpairs = 0; p.n_gchunks = 0; return p; }
+    p.mesh_split = msplit;
     if (n == 1 && sub == 1) { len = (N + XRT_TILE - 1) / XRT_TILE * XRT_TILE; sublen = len; }      // whole runs through the SEG kernels
     p.n_seg = (int)n; p.seg_len = len; p.n_sub = (int)sub; p.sub_len = sublen;
     if (!bragg) {
@@ -2699,7 +2982,7 @@ static SegPlan plan_segments(const xrt_scene_t* sc, int n_runs)
     }
     return p;
 }
-static bool seg_active(const SegPlan& p) { return p.n_seg > 1 || p.n_sub > 1 || p.n_gchunks > 0; }
+static bool seg_active(const SegPlan& p) { return p.n_seg > 1 || p.n_sub > 1 || p.n_gchunks > 0 || p.mesh_split; }
 // jobs of a run: [segment][source head], the chunk heads, the chunk heads of the Gaussian candidate stream
 static int seg_jobs(const xrt_scene_t* sc, const SegPlan& p) { return p.n_seg * count_heads(sc) + p.n_chunk_heads + p.n_gchunks; }
 // segmented runs: [dst heads n_runs x n_jobs][polys][offsets][unit counts / flags][gauss: values, chunk counts, words]
@@ -2733,10 +3016,19 @@ static size_t seg_bytes(const xrt_scene_t* sc, int n_runs)
 #define XRT_CAND_BUDGET      (48ull << 30)
 #define XRT_CAND_BUDGET_TAIL (2ull << 30)       // for the < 256 runs an unsegmented launch leaves to a second pass
 static size_t cand_capacity(const xrt_scene_t* sc) { return ((size_t)(sc->source.intensity > 0 ? sc->source.intensity : 1) + 255) & ~(size_t)255; }
+static size_t mesh_split_off_aux(const xrt_scene_t* sc, int n_runs) { return al256((size_t)n_runs * cand_capacity(sc) * 80); }
+static size_t mesh_split_off_batch_alive(const xrt_scene_t* sc, int n_runs) { return mesh_split_off_aux(sc, n_runs) + al256((size_t)n_runs * cand_capacity(sc) * 4); }
+static size_t mesh_split_off_unit_alive(const xrt_scene_t* sc, int n_runs) { return mesh_split_off_batch_alive(sc, n_runs) + al256((size_t)n_runs * (cand_capacity(sc) / 64) * 4); }
 static size_t cand_bytes(const xrt_scene_t* sc, int n_runs, size_t budget)
 {
     const SegPlan p = plan_segments(sc, n_runs);
-    if (!seg_active(p) || p.n_seg * p.n_sub <= 1 || bragg_element(sc) < 0 || env_on("XICSRT_SEG_TWO_PASS")) return 0;
+    if (!seg_active(p) || bragg_element(sc) < 0 || env_on("XICSRT_SEG_TWO_PASS")) return 0;
+    if (p.mesh_split) {
+        // split phases: 10 doubles (+ the normal) and the face per ray, the rays left alive per 64 and per unit; twice the budget
+        const size_t b = mesh_split_off_unit_alive(sc, n_runs) + al256(sizeof(uint32_t) * (size_t)n_runs * (size_t)p.n_seg * (size_t)p.n_sub) + 256;
+        return b <= 2 * budget ? b : 0;
+    }
+    if (p.n_seg * p.n_sub <= 1) return 0;
     const size_t b = al256((size_t)n_runs * cand_capacity(sc) * 64) + 256;
     return b <= budget ? b : 0;
 }
@@ -2994,7 +3286,7 @@ static bool lds_bins_wanted(const xrt_scene_t* sc, bool images, bool hist)
 }
 // Bragg batches of 256 candidates (all four waves busy, half as many batches) when the larger ray buffer
 // does not cost a workgroup per CU (160 KiB of LDS), else 128
-static size_t plan_queue(const KScene& ks, int n_src_heads, bool ext, bool hist, KArgs* a, uint32_t lbins_words = 0)
+static size_t plan_queue(const KScene& ks, int n_src_heads, bool ext, bool hist, KArgs* a, uint32_t lbins_words = 0, int wmax_given = 0)
 {
     const bool has_wl = !(ks.src.wavelength_dist == XRT_WL_CONST && !ks.src.has_velocity);
     a->lbins_words = lbins_words;
@@ -3006,7 +3298,7 @@ static size_t plan_queue(const KScene& ks, int n_src_heads, bool ext, bool hist,
     const size_t l256 = lds_bytes(n_src_heads, ext, hist, has_wl, XRT_QCAP_256);
     const size_t cu = 160u * 1024u;
     size_t w128 = cu / l128, w256 = cu / l256;
-    const size_t wmax = ext ? 2 : 4;            // what the register budget of the variant allows anyway
+    const size_t wmax = wmax_given > 0 ? (size_t)wmax_given : (ext ? 2 : 4);            // what the register budget of the variant allows anyway
     if (w128 > wmax) w128 = wmax;
     if (w256 > wmax) w256 = wmax;
     const bool big = w256 >= w128 && w256 >= 1 && !getenv("XICSRT_BRAGG_BATCH_128");
@@ -3022,6 +3314,7 @@ static int upload_meshes(const xrt_scene_t* sc, char* ws, int n_runs, KScene* ks
     bool synced = false;
     for (int e = 0; e < sc->n_optics; e++) {
         ks->opt[e].mesh = nullptr;
+        ks->opt[e].mesh_lds_bytes = 0;
         if (sc->optics[e].shape != XRT_SHAPE_MESH) continue;
         // The packed tables are host temporaries, copied synchronously; an earlier call on `stream` may still be
         // reading this part of the workspace (with another layout): wait for it first.  (Mesh scenes only; every other
@@ -3242,6 +3535,36 @@ static int upload_meshes(const xrt_scene_t* sc, char* ws, int n_runs, KScene* ks
             k.ct_values = (gdp)put(m->ct_values, 4 * P * 8);
             k.ct_grad = (gdp)put(m->ct_grad, 8 * P * 8);
             k.ct_vertex_simplex = (gip)put(m->ct_vertex_simplex, P * 4);
+            // per simplex what the evaluation needs of it alone (SciPy _clough_tocher_2d_single: the edge vectors and, per
+            // neighbour, the weight g from the neighbour's centroid in this simplex' barycentric coordinates), with the
+            // operations ct_shared used to make per ray (this file is compiled without contraction, host and device)
+            std::vector<double> sr(T * 12, 0.0);
+            for (size_t si = 0; si < T; si++) {
+                const int32_t* v = m->ct_simplices + 3 * si;
+                const double* pts = m->ct_points;
+                double* o = &sr[12 * si];
+                int32_t iv[4] = {v[0], v[1], v[2], 0};
+                memcpy(o, iv, 16);
+                o[2] = pts[2 * v[1]] - pts[2 * v[0]]; o[3] = pts[2 * v[1] + 1] - pts[2 * v[0] + 1];
+                o[4] = pts[2 * v[2]] - pts[2 * v[1]]; o[5] = pts[2 * v[2] + 1] - pts[2 * v[1] + 1];
+                o[6] = pts[2 * v[0]] - pts[2 * v[2]]; o[7] = pts[2 * v[0] + 1] - pts[2 * v[2] + 1];
+                const double* Tm = m->ct_transform + 6 * si;
+                for (int kk = 0; kk < 3; kk++) {
+                    const int itri = m->ct_neighbors[3 * si + kk];
+                    if (itri == -1) { o[8 + kk] = -1. / 2; continue; }
+                    const int32_t* w = m->ct_simplices + 3 * (size_t)itri;
+                    volatile double y0 = (pts[2 * w[0]] + pts[2 * w[1]] + pts[2 * w[2]]) / 3;
+                    volatile double y1 = (pts[2 * w[0] + 1] + pts[2 * w[1] + 1] + pts[2 * w[2] + 1]) / 3;
+                    double c[3];
+                    c[2] = 1.0;
+                    c[0] = 0.0; c[0] += Tm[0] * (y0 - Tm[4]); c[0] += Tm[1] * (y1 - Tm[5]); c[2] -= c[0];
+                    c[1] = 0.0; c[1] += Tm[2] * (y0 - Tm[4]); c[1] += Tm[3] * (y1 - Tm[5]); c[2] -= c[1];
+                    if (kk == 0)      o[8 + kk] = (2 * c[2] + c[1] - 1) / (2 - 3 * c[2] - 3 * c[1]);
+                    else if (kk == 1) o[8 + kk] = (2 * c[0] + c[2] - 1) / (2 - 3 * c[0] - 3 * c[2]);
+                    else              o[8 + kk] = (2 * c[1] + c[0] - 1) / (2 - 3 * c[1] - 3 * c[0]);
+                }
+            }
+            k.ct_srec = (const XRT_G1 d4v*)put(sr.data(), sr.size() * 8);
         }
         if (m->n_coarse_faces > 0 && P > 0) {
             // x-y bucket grid for the nearest-point search, about one point per bucket
@@ -3270,6 +3593,7 @@ static int upload_meshes(const xrt_scene_t* sc, char* ws, int n_runs, KScene* ks
                 std::vector<KCellRec> cells(NC);
                 for (size_t c = 0; c < NC; c++) { cells[c].x = cells[c].y = cells[c].z = 0.0; cells[c].idx = -1; cells[c].next = -1; }
                 std::vector<int32_t> tail(NC, -1);                // last record of every bucket's chain
+                std::vector<int32_t> pslot(P, -1);                // where a point's record went
                 for (size_t i = 0; i < P; i++) {                  // ascending point index along a chain
                     double fx = floor((m->points[3 * i] - k.grid_x0) * k.grid_ihx), fy = floor((m->points[3 * i + 1] - k.grid_y0) * k.grid_ihy);
                     if (!(fx >= 0.0)) fx = 0.0;
@@ -3280,13 +3604,48 @@ static int upload_meshes(const xrt_scene_t* sc, char* ws, int n_runs, KScene* ks
                     r.x = m->points[3 * i]; r.y = m->points[3 * i + 1]; r.z = m->points[3 * i + 2]; r.idx = (int32_t)i; r.next = -1;
                     if (tail[c] < 0) { cells[c] = r; tail[c] = (int32_t)c; }
                     else { cells[(size_t)tail[c]].next = (int32_t)cells.size(); tail[c] = (int32_t)cells.size(); cells.push_back(r); }
+                    pslot[i] = tail[c];
                 }
                 k.cells = (const XRT_G1 d4v*)put(cells.data(), cells.size() * sizeof(KCellRec));
+                // ---- the LDS form (see KMesh.lds_pf): every vertex of every face must be one of the points ----------
+                k.n_cells = (int32_t)cells.size();
+                const size_t n_first = (size_t)k.n_first;
+                const size_t lds_need = cells.size() * sizeof(KCellRec) + P * 16 + F * 8 + (n_first + 1) * 80 + 64;
+                if (F < 0xffff && cells.size() < 0xffff && lds_need <= XRT_MESH_LDS_MAX && !env_on("XICSRT_NO_MESH_LDS")) {
+                    struct Key { uint64_t a, b, c; bool operator==(const Key& o) const { return a == o.a && b == o.b && c == o.c; } };
+                    struct KeyHash { size_t operator()(const Key& q) const { return (size_t)(q.a * 0x9e3779b97f4a7c15ull ^ (q.b + 0x7f4a7c15ull) * 0xbf58476d1ce4e5b9ull ^ (q.c * 0x94d049bb133111ebull)); } };
+                    std::unordered_map<Key, int32_t, KeyHash> where;
+                    where.reserve(P * 2);
+                    auto key_of = [](const double* v) { Key q; memcpy(&q.a, v, 8); memcpy(&q.b, v + 1, 8); memcpy(&q.c, v + 2, 8); return q; };
+                    for (size_t i = 0; i < P; i++) where.emplace(key_of(m->points + 3 * i), pslot[i]);
+                    std::vector<uint16_t> fv(F * 4, 0), pf16(P * 8, 0xffff);
+                    bool all = true;
+                    for (size_t i = 0; i < F && all; i++) {
+                        const double* vs[3] = {m->p0 + 3 * i, m->p1 + 3 * i, m->p2 + 3 * i};
+                        for (int j = 0; j < 3 && all; j++) {
+                            const auto it = where.find(key_of(vs[j]));
+                            if (it == where.end() || it->second < 0) all = false;
+                            else fv[4 * i + j] = (uint16_t)it->second;
+                        }
+                    }
+                    for (size_t i = 0; i < P; i++)
+                        for (int j = 0; j < 8; j++)
+                            if (m->p_faces_mask[(size_t)j * P + i]) {
+                                const int32_t f = m->p_faces_idx[(size_t)j * P + i];
+                                if (f < 0 || (size_t)f >= F) all = false; else pf16[8 * i + j] = (uint16_t)f;
+                            }
+                    if (all) {
+                        k.lds_pf = (const uint16_t*)put(pf16.data(), pf16.size() * 2);
+                        k.lds_fv = (const uint16_t*)put(fv.data(), fv.size() * 2);
+                        k.lds_bytes = (int32_t)lds_need;
+                    }
+                }
             }
         }
         if (put_err != hipSuccess) return fail(-10, "copy of the mesh tables to the device: %s", hipGetErrorString(put_err));
         HIP_TRY(hipMemcpy(base, &k, sizeof(KMesh), hipMemcpyHostToDevice));
         ks->opt[e].mesh = reinterpret_cast<const KMesh*>(base);
+        ks->opt[e].mesh_lds_bytes = k.lds_bytes;
         base += mesh_bytes(m);
     }
     return 0;
@@ -3567,7 +3926,11 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
         return 0;
     }
 #endif
-    const SegPlan plan = ahead > 0 ? plan_segments(sc, n_runs) : SegPlan{1, 0, 0, 0, 0};
+    SegPlan plan = ahead > 0 ? plan_segments(sc, n_runs) : SegPlan{1, 0, 0, 0, 0};
+    if (plan.mesh_split && hist) {          // (histories: the routes without the split)
+        if (plan.n_seg * plan.n_sub == 1 && plan.n_gchunks == 0) plan = SegPlan{1, 0, 0, 0, 0};
+        else plan.mesh_split = false;
+    }
     if (seg_active(plan)) {
         // ---- segmented runs -------------------------------------------------------------------------
         g_paths |= XRT_PATH_FUSED | XRT_PATH_SEGMENTED | XRT_PATH_JUMP;
@@ -3706,7 +4069,21 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
         a.n_sub = M; a.sub_len = plan.sub_len;
         // one pass (candidates parked in HBM behind everything else) when the workspace holds them
         const size_t cand_need = cand_bytes(sc, n_runs, XRT_CAND_BUDGET);
-        const bool one_pass = be >= 0 && S * M > 1 && cand_need > 0 && ws_base_bytes(sc, n_runs) + cand_need <= ws_bytes;
+        const bool one_pass = be >= 0 && (S * M > 1 || plan.mesh_split) && cand_need > 0 && ws_base_bytes(sc, n_runs) + cand_need <= ws_bytes;
+        const bool split = one_pass && plan.mesh_split;
+        if (split) {
+            char* cb = ws + ws_base_bytes(sc, n_runs);
+            a.cand = reinterpret_cast<double*>(cb);
+            a.cand_id = nullptr;
+            a.cand_aux = reinterpret_cast<uint32_t*>(cb + mesh_split_off_aux(sc, n_runs));
+            a.batch_alive = reinterpret_cast<uint32_t*>(cb + mesh_split_off_batch_alive(sc, n_runs));
+            a.unit_alive = reinterpret_cast<uint32_t*>(cb + mesh_split_off_unit_alive(sc, n_runs));
+            a.cand_cap = (int64_t)cand_capacity(sc);
+            a.unit_flag = d_cnt;
+            HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(uint32_t) * (size_t)n_runs * (size_t)S * (size_t)M, stream));
+            HIP_TRY(hipMemsetAsync(a.unit_alive, 0, sizeof(uint32_t) * (size_t)n_runs * (size_t)S * (size_t)M, stream));
+            g_paths |= XRT_PATH_ONE_PASS | XRT_PATH_MESH_SPLIT;
+        } else
         if (one_pass) {
             const size_t cap = cand_capacity(sc);
             char* cb = ws + ws_base_bytes(sc, n_runs);
@@ -3743,8 +4120,54 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
         int variant = needs_ext(sc) ? 2 : (needs_full(sc) ? 1 : 0);
         if (variant == 0 && n_gch > 0) variant = 3;         // lean geometry, wavelength per ray from the prepared array
         if (variant == 0 && lds_bins_wanted(sc, a.images != nullptr, hist)) variant = 4;
-        const size_t lds = plan_queue(ks, nh, variant == 2, hist, &a, variant == 4 ? (uint32_t)((sc->image_bins + 1) / 2) : 0u);
+        const size_t lds = plan_queue(ks, nh, variant == 2, hist, &a, variant == 4 ? (uint32_t)((sc->image_bins + 1) / 2) : 0u, split ? 4 : 0);
         if (variant == 4) g_paths |= XRT_PATH_LDS_BINS;
+        if (split) {
+            // first phase, the rest of the mesh intersection for every parked ray, second phase
+            a.mode = 2;
+            HIP_TRY(hipMemsetAsync(ws, 0, 64, stream));
+            int st = launch_variant<false, 2, 3>(device_scene(ws), a, n_runs, lds, stream);
+            if (st) return st;
+            const uint32_t bpu = (uint32_t)(plan.sub_len / XRT_TILE);
+            const unsigned long long blocks = (unsigned long long)n_runs * (unsigned long long)(S * M) * bpu;
+            if (blocks > 0x7fffffffull) return fail(-5, "%s", "mesh split: too many blocks");
+            int ti = -1;
+            if (timing_on && timing_n < TIMING_MAX) {
+                ti = timing_n++;
+                HIP_TRY(hipEventCreate(&timing_ev[ti][0]));
+                HIP_TRY(hipEventCreate(&timing_ev[ti][1]));
+                HIP_TRY(hipEventRecord(timing_ev[ti][0], stream));
+            }
+            KArgs am = a;
+            const bool ct = sc->optics[be].mesh && sc->optics[be].mesh->interpolate;
+            const int lds_m = ks.opt[be].mesh_lds_bytes;
+            if (lds_m > 0) {
+                // the mesh's tables in LDS: one workgroup of 1024 per CU, blocks of 1024 rays round robin
+                static thread_local int c_dev3 = -1, c_cus3 = 256;
+                if (c_dev3 != dev_now) { HIP_TRY(hipDeviceGetAttribute(&c_cus3, hipDeviceAttributeMultiprocessorCount, dev_now)); c_dev3 = dev_now; }
+                const uint32_t bpu4 = (bpu + 3u) / 4u;
+                const unsigned long long items = (unsigned long long)n_runs * (unsigned long long)(S * M) * bpu4;
+                const unsigned grid = (unsigned)(items < (unsigned long long)c_cus3 ? items : (unsigned long long)c_cus3);
+                if (ct) {
+                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(xrt_mesh_rest_lds_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_m));
+                    hipLaunchKernelGGL((xrt_mesh_rest_lds_kernel<true>), dim3(grid), dim3(XRT_MESH_LDS_THREADS), (size_t)lds_m, stream, device_scene(ws), am, be, bpu4, (uint32_t)(n_runs * S * M));
+                    HIP_TRY(hipGetLastError());
+                    hipLaunchKernelGGL(xrt_mesh_ct_kernel, dim3((unsigned)blocks), dim3(XRT_TILE), 0, stream, device_scene(ws), am, be, bpu);
+                } else {
+                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(xrt_mesh_rest_lds_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_m));
+                    hipLaunchKernelGGL((xrt_mesh_rest_lds_kernel<false>), dim3(grid), dim3(XRT_MESH_LDS_THREADS), (size_t)lds_m, stream, device_scene(ws), am, be, bpu4, (uint32_t)(n_runs * S * M));
+                }
+            } else
+            if (ct)
+                hipLaunchKernelGGL((xrt_mesh_rest_kernel<true>), dim3((unsigned)blocks), dim3(XRT_TILE), 0, stream, device_scene(ws), am, be, bpu);
+            else
+                hipLaunchKernelGGL((xrt_mesh_rest_kernel<false>), dim3((unsigned)blocks), dim3(XRT_TILE), 0, stream, device_scene(ws), am, be, bpu);
+            HIP_TRY(hipGetLastError());
+            if (ti >= 0) HIP_TRY(hipEventRecord(timing_ev[ti][1], stream));
+            HIP_TRY(hipMemsetAsync(ws, 0, 64, stream));
+            st = launch_variant<false, 2, 4>(device_scene(ws), a, n_runs, lds, stream);
+            return st;
+        }
         // (a run that is one unit has nothing in front of it: no count pass)
         for (int mode = ((be >= 0 && S * M > 1 && !one_pass) ? 1 : 2); mode <= 2; mode++) {
             a.mode = mode;
