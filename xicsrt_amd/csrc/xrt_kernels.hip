@@ -141,6 +141,14 @@ struct KMesh {               // device pointers, see xrt_mesh_t
     // The first optic behind a point source sees every ray leave from ONE point O: with m = e2 x e1, E02 = (p0-O) x (p2-O),
     // E10 = (p1-O) x (p0-O) the Moller-Trumbore quantities are f = d.m, u f = d.E02, v f = d.E10 -- three dot products per face.
     const double* pt_rec;           // [n_first + 1][12] m, E02, E10, |m|^2 (+inf: degenerate), 2 spare; or null
+    // ... and a grid over the directions from O (dg_n = 0: none): with an orthonormal frame ex, ey, ez about the mean
+    // direction to the faces, a ray of direction d lands at (d.ex / d.ez, d.ey / d.ez); a cell of the dg_n x dg_n grid
+    // over the faces' images lists the <= 8 faces whose image (with a margin) touches it, ascending; 0xff: no
+    // further face, a first byte of 0xfe: more than eight (the ray walks every face).  The first phase of a split launch
+    // keeps the cells and pt_rec in LDS.
+    int32_t dg_n, dg_pad;
+    double  dg_x0, dg_y0, dg_ihx, dg_ihy, dg_ex[3], dg_ey[3], dg_ez[3];
+    const uint32_t* dg_cells;       // [dg_n * dg_n][2]: eight face numbers
     // plane form of EVERY face (as plane_rec) for the second pass around the nearest point; [13]: how far outside (in
     // barycentric units) a point must lie for the reference's area test (diff < 1e-10) to fail for sure
     const XRT_G1 d4v* plane2_rec;   // [n_faces][16] or null (no second pass)
@@ -178,6 +186,7 @@ struct KOptic {
     double  scr2_tail, inv_two_d;               // bound on p for |sin(inc - bragg)| >= 0.01; 1 / (2 d)
     int32_t scr2_ok;
     int32_t mesh_lds_bytes;             // host side: KMesh.lds_bytes of `mesh` (which launch finishes a split mesh intersection)
+    int32_t mesh_dir_bytes, pad4;       // host side: LDS bytes of the mesh's direction grid (KMesh.dg_n), 0: none
 };
 
 struct KScene {
@@ -1116,6 +1125,7 @@ struct KArgs {
     // SEG == 3 / 4 (the phases of SEG == 2 as launches of their own around xrt_mesh_rest_kernel, a mesh crystal): that
     // kernel finishes the intersection of every parked ray and leaves per ray the hit point, the normal and in cand_aux
     // XRT_CAND_DEAD for a ray that is out; per 64 rays and per unit the number left alive (= Bragg draws)
+    uint32_t dir_lds_bytes, pad_dir;    // SEG == 3: bytes of the direction grid's tables behind the workgroup's other LDS (0: none; KMesh.dg_n)
     uint32_t* batch_alive;              // [n_runs][cand_cap / 64]
     uint32_t* unit_alive;               // [n_runs][n_seg * n_sub], zero before the launch
     unsigned long long* dbg;            // development: [units][8] wall-clock stamps of a unit's phases (null: none)
@@ -1266,6 +1276,24 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
     // of a cone of rays misses the mesh altogether, and a wave of unrelated rays executes the union of its lanes'
     // work); the rays that hit a face wait in the Bragg queue and get the rest -- nearest point, second pass,
     // interpolation, bounds -- on the dense lanes of a Bragg batch, in ray order, just in front of their Bragg test.
+    // SEG == 3: the direction grid of a mesh behind a point source and its face records (KMesh.dg_n, pt_rec) in LDS
+    const __attribute__((address_space(3))) double* l_dpt = nullptr;
+    const __attribute__((address_space(3))) uint32_t* l_dcells = nullptr;
+    if constexpr (SEG == 3) {
+        if (args.dir_lds_bytes > 0u && be >= 0) {
+            MeshRef Mh = *(const XRT_C4 KMesh*)uniform_u64((uint64_t)SC.opt[be].mesh);
+            double* tp = reinterpret_cast<double*>(lbins);
+            const uint32_t n_pt = 12u * ((uint32_t)Mh.n_first + 1u), n_c = 2u * (uint32_t)(Mh.dg_n * Mh.dg_n);
+            uint32_t* tc = reinterpret_cast<uint32_t*>(tp + n_pt);
+            const XRT_G1 double* gp = (const XRT_G1 double*)(uint64_t)Mh.pt_rec;
+            const XRT_G1 uint32_t* gc = (const XRT_G1 uint32_t*)(uint64_t)Mh.dg_cells;
+            for (uint32_t i = (uint32_t)tid; i < n_pt; i += XRT_TILE) tp[i] = gp[i];
+            for (uint32_t i = (uint32_t)tid; i < n_c; i += XRT_TILE) tc[i] = gc[i];
+            l_dpt = (const __attribute__((address_space(3))) double*)tp;
+            l_dcells = (const __attribute__((address_space(3))) uint32_t*)tc;
+            lds_barrier();
+        }
+    }
     bool mesh_pre = false;
     // (SEG == 2 counts a unit's candidates in its first phase: the whole intersection runs there)
     if constexpr (EXT && SEG != 2) mesh_pre = be >= 0 && SC.opt[be].shape == XRT_SHAPE_MESH;      // (SEG >= 3: always, by the host's choice of route)
@@ -1558,7 +1586,14 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
                             bool hit;
                             if (is_mesh && e == be && mesh_pre && !counting) {
                                 // queued with its (local-frame) origin and the face of the first pass; see mesh_pre
-                                aux = mesh_first(op.mesh, ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z);
+                                bool by_grid = false;
+                                if constexpr (SEG == 3) {
+                                    if (l_dpt) {
+                                        aux = mesh_first_dir(op.mesh, l_dcells, l_dpt, ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z);
+                                        by_grid = true;
+                                    }
+                                }
+                                if (!by_grid) aux = mesh_first(op.mesh, ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z);
                                 hit = aux >= 0;
                                 X = ray.o;
                                 alive = hit;
@@ -2779,6 +2814,7 @@ static size_t mesh_bytes(const xrt_mesh_t* m)
     b += al256((n_first + 1) * 96);                                   // point-source form of the first pass
     if (Cn > 0) b += al256(F * 128);                                  // plane form of every face (second pass)
     b += al256(P * 16) + al256(F * 8);                                // 16-bit tables of the LDS form
+    b += al256(32 * 32 * 8);                                          // direction grid of the point-source form
     return b;
 }
 static size_t meshes_bytes(const xrt_scene_t* sc)
@@ -3315,6 +3351,7 @@ static int upload_meshes(const xrt_scene_t* sc, char* ws, int n_runs, KScene* ks
     for (int e = 0; e < sc->n_optics; e++) {
         ks->opt[e].mesh = nullptr;
         ks->opt[e].mesh_lds_bytes = 0;
+        ks->opt[e].mesh_dir_bytes = 0;
         if (sc->optics[e].shape != XRT_SHAPE_MESH) continue;
         // The packed tables are host temporaries, copied synchronously; an earlier call on `stream` may still be
         // reading this part of the workspace (with another layout): wait for it first.  (Mesh scenes only; every other
@@ -3431,6 +3468,103 @@ static int upload_meshes(const xrt_scene_t* sc, char* ws, int n_runs, KScene* ks
                         w[9] = mm;
                     }
                     k.pt_rec = (const double*)put(pt.data(), pt.size() * 8);
+                    // ---- direction grid (see KMesh.dg_n) ----
+                    k.dg_n = 0;
+                    if (n_first >= 8 && n_first < 0xfe && !env_on("XICSRT_NO_DIR_GRID")) {
+                        double ez[3] = {0, 0, 0};
+                        bool ok = true;
+                        for (size_t i = 0; i < n_first; i++)
+                            for (int c = 0; c < 3; c++) ez[c] += (q0[3 * i + c] + (q1[3 * i + c] + q2[3 * i + c]) / 3.0) - Ol[c];
+                        const double zl = sqrt(ez[0] * ez[0] + ez[1] * ez[1] + ez[2] * ez[2]);
+                        ok = std::isfinite(zl) && zl > 0.0;
+                        double ex[3] = {0, 0, 0}, ey[3] = {0, 0, 0};
+                        if (ok) {
+                            for (int c = 0; c < 3; c++) ez[c] /= zl;
+                            const int least = fabs(ez[0]) <= fabs(ez[1]) ? (fabs(ez[0]) <= fabs(ez[2]) ? 0 : 2) : (fabs(ez[1]) <= fabs(ez[2]) ? 1 : 2);
+                            double t[3] = {0, 0, 0};
+                            t[least] = 1.0;
+                            ex[0] = t[1] * ez[2] - t[2] * ez[1]; ex[1] = t[2] * ez[0] - t[0] * ez[2]; ex[2] = t[0] * ez[1] - t[1] * ez[0];
+                            const double xl = sqrt(ex[0] * ex[0] + ex[1] * ex[1] + ex[2] * ex[2]);
+                            for (int c = 0; c < 3; c++) ex[c] /= xl;
+                            ey[0] = ez[1] * ex[2] - ez[2] * ex[1]; ey[1] = ez[2] * ex[0] - ez[0] * ex[2]; ey[2] = ez[0] * ex[1] - ez[1] * ex[0];
+                        }
+                        // images of the vertices; every vertex well in front of O along ez, no face seen edge-on
+                        std::vector<double> img(n_first * 6);
+                        double lo2[2] = {HUGE_VAL, HUGE_VAL}, hi2[2] = {-HUGE_VAL, -HUGE_VAL};
+                        for (size_t i = 0; i < n_first && ok; i++) {
+                            for (int vtx = 0; vtx < 3 && ok; vtx++) {
+                                double w[3];
+                                for (int c = 0; c < 3; c++) w[c] = q0[3 * i + c] + (vtx == 1 ? q1[3 * i + c] : vtx == 2 ? q2[3 * i + c] : 0.0) - Ol[c];
+                                const double wl = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+                                const double wz = w[0] * ez[0] + w[1] * ez[1] + w[2] * ez[2];
+                                ok = std::isfinite(wl) && wl > 0.0 && wz > 0.2 * wl;
+                                if (!ok) break;
+                                const double px = (w[0] * ex[0] + w[1] * ex[1] + w[2] * ex[2]) / wz, py = (w[0] * ey[0] + w[1] * ey[1] + w[2] * ey[2]) / wz;
+                                img[6 * i + 2 * vtx] = px; img[6 * i + 2 * vtx + 1] = py;
+                                if (px < lo2[0]) lo2[0] = px;
+                                if (px > hi2[0]) hi2[0] = px;
+                                if (py < lo2[1]) lo2[1] = py;
+                                if (py > hi2[1]) hi2[1] = py;
+                            }
+                            if (!ok) break;
+                            const double* g = &img[6 * i];
+                            const double ax = g[2] - g[0], ay = g[3] - g[1], bx = g[4] - g[0], by = g[5] - g[1];
+                            const double area2 = fabs(ax * by - ay * bx), len2 = fmax(ax * ax + ay * ay, bx * bx + by * by);
+                            ok = area2 > 1e-3 * len2;                   // (an image that is a sliver: a face seen nearly edge-on)
+                        }
+                        const double extx = hi2[0] - lo2[0], exty = hi2[1] - lo2[1];
+                        ok = ok && std::isfinite(extx) && std::isfinite(exty) && extx > 0.0 && exty > 0.0;
+                        if (ok) {
+                            int G = 4 * (int)ceil(sqrt((double)n_first));
+                            if (G < 8) G = 8;
+                            if (G > 32) G = 32;
+                            const double mx = 1e-6 * extx, my = 1e-6 * exty;       // (a miss by this much in the image is a miss by >= 1e-6 in barycentric units)
+                            const double x0 = lo2[0] - 2 * mx, y0 = lo2[1] - 2 * my, hx = (extx + 4 * mx) / G, hy = (exty + 4 * my) / G;
+                            std::vector<uint32_t> cellsd((size_t)G * G * 2, 0xffffffffu);
+                            std::vector<int> cnt((size_t)G * G, 0);
+                            for (size_t i = 0; i < n_first; i++) {              // ascending face index within a cell
+                                const double* g = &img[6 * i];
+                                const double fx0 = fmin(g[0], fmin(g[2], g[4])) - mx, fx1 = fmax(g[0], fmax(g[2], g[4])) + mx;
+                                const double fy0 = fmin(g[1], fmin(g[3], g[5])) - my, fy1 = fmax(g[1], fmax(g[3], g[5])) + my;
+                                int cx0 = (int)floor((fx0 - x0) / hx), cx1 = (int)floor((fx1 - x0) / hx);
+                                int cy0 = (int)floor((fy0 - y0) / hy), cy1 = (int)floor((fy1 - y0) / hy);
+                                if (cx0 < 0) cx0 = 0;
+                                if (cy0 < 0) cy0 = 0;
+                                if (cx1 > G - 1) cx1 = G - 1;
+                                if (cy1 > G - 1) cy1 = G - 1;
+                                for (int cy = cy0; cy <= cy1; cy++)
+                                    for (int cx = cx0; cx <= cx1; cx++) {
+                                        // the cell (with the margin) against the three edges of the image: wholly beyond one -> no overlap
+                                        const double bx0 = x0 + cx * hx - mx, bx1 = x0 + (cx + 1) * hx + mx, by0 = y0 + cy * hy - my, by1 = y0 + (cy + 1) * hy + my;
+                                        bool apart = false;
+                                        for (int ed = 0; ed < 3 && !apart; ed++) {
+                                            const double *pa = g + 2 * ed, *pb = g + 2 * ((ed + 1) % 3), *pc = g + 2 * ((ed + 2) % 3);
+                                            const double nxe = pb[1] - pa[1], nye = pa[0] - pb[0];                    // a normal of edge a-b
+                                            const double side = nxe * (pc[0] - pa[0]) + nye * (pc[1] - pa[1]);       // where the third vertex lies
+                                            const double sg = side >= 0.0 ? 1.0 : -1.0;
+                                            const double tolr = 1e-9 * (fabs(nxe) * (fabs(bx0) + fabs(bx1) + fabs(pa[0])) + fabs(nye) * (fabs(by0) + fabs(by1) + fabs(pa[1])));
+                                            const double corners[4][2] = {{bx0, by0}, {bx1, by0}, {bx0, by1}, {bx1, by1}};
+                                            bool all_out = true;
+                                            for (int q = 0; q < 4; q++)
+                                                if (sg * (nxe * (corners[q][0] - pa[0]) + nye * (corners[q][1] - pa[1])) >= -tolr) all_out = false;
+                                            apart = all_out;
+                                        }
+                                        if (apart) continue;
+                                        const size_t c = (size_t)cy * G + cx;
+                                        if (cnt[c] < 8) {
+                                            uint32_t& wd = cellsd[2 * c + (cnt[c] >> 2)];
+                                            const int sh = 8 * (cnt[c] & 3);
+                                            wd = (wd & ~(0xffu << sh)) | ((uint32_t)i << sh);
+                                        }
+                                        cnt[c]++;
+                                    }
+                            }
+                            for (size_t c = 0; c < cnt.size(); c++) if (cnt[c] > 8) cellsd[2 * c] = 0xfffffffeu;
+                            k.dg_n = G; k.dg_x0 = x0; k.dg_y0 = y0; k.dg_ihx = 1.0 / hx; k.dg_ihy = 1.0 / hy;
+                            for (int c = 0; c < 3; c++) { k.dg_ex[c] = ex[c]; k.dg_ey[c] = ey[c]; k.dg_ez[c] = ez[c]; }
+                            k.dg_cells = (const uint32_t*)put(cellsd.data(), cellsd.size() * 4);
+                        }
+                    }
                 }
             }
             // ---- x-y grid over these faces (see KMesh.fg_n) ----------------------------------------------------
@@ -3646,6 +3780,7 @@ static int upload_meshes(const xrt_scene_t* sc, char* ws, int n_runs, KScene* ks
         HIP_TRY(hipMemcpy(base, &k, sizeof(KMesh), hipMemcpyHostToDevice));
         ks->opt[e].mesh = reinterpret_cast<const KMesh*>(base);
         ks->opt[e].mesh_lds_bytes = k.lds_bytes;
+        ks->opt[e].mesh_dir_bytes = k.dg_n > 0 ? (int32_t)(((size_t)k.n_first + 1) * 96 + (size_t)k.dg_n * k.dg_n * 8) : 0;
         base += mesh_bytes(m);
     }
     return 0;
@@ -4126,7 +4261,13 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
             // first phase, the rest of the mesh intersection for every parked ray, second phase
             a.mode = 2;
             HIP_TRY(hipMemsetAsync(ws, 0, 64, stream));
-            int st = launch_variant<false, 2, 3>(device_scene(ws), a, n_runs, lds, stream);
+            // (the first phase needs the record buffer for the compactions of one tile only, and room for the direction grid)
+            KArgs a3 = a;
+            a3.qcap = XRT_TILE; a3.bragg_batch = 128u;
+            a3.dir_lds_bytes = (uint32_t)(ks.opt[be].mesh_dir_bytes > 0 ? ks.opt[be].mesh_dir_bytes : 0);
+            const bool has_wl3 = !(ks.src.wavelength_dist == XRT_WL_CONST && !ks.src.has_velocity);
+            const size_t lds3 = lds_bytes(nh, true, false, has_wl3, XRT_TILE) + a3.dir_lds_bytes;
+            int st = launch_variant<false, 2, 3>(device_scene(ws), a3, n_runs, lds3, stream);
             if (st) return st;
             const uint32_t bpu = (uint32_t)(plan.sub_len / XRT_TILE);
             const unsigned long long blocks = (unsigned long long)n_runs * (unsigned long long)(S * M) * bpu;
