@@ -203,6 +203,38 @@ def test_segmented_runs_equal_reference(name, segments, route, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('route', ['split', 'split_tables_in_global', 'split_every_face', 'fused'])
+@pytest.mark.parametrize('name', ['E_cfg5_mesh_flat_1e5', 'E_cfg5_mesh_interp_1e5', 'E_mesh_interp_counts', 'E_mesh_norefine_counts',
+                                  'E_mesh_81_coarse17_counts'])
+def test_mesh_crystal_routes_equal_reference(name, route, monkeypatch):
+    """A mesh crystal that makes the Bragg test goes through three launches -- rays up to the first pass over the faces
+    (behind a point source: through the grid over the directions), the rest of ShapeMesh.intersect per parked ray (small
+    meshes: tables in LDS, faces classified from their vertices; interpolation in a launch of its own), Bragg test and
+    the elements behind.  Every variant of it, and the one-kernel route, give the reference's integers."""
+    if route == 'fused':
+        monkeypatch.setenv('XICSRT_NO_MESH_SPLIT', '1')
+    if route == 'split_tables_in_global':
+        monkeypatch.setenv('XICSRT_NO_MESH_LDS', '1')
+    if route == 'split_every_face':
+        monkeypatch.setenv('XICSRT_NO_DIR_GRID', '1')
+    cfg, gold = helpers.load_golden(name)
+    config, elements, flat = helpers.build(cfg)
+    g = config['general']
+    seeds = xrt.run_seeds(g['random_seed'], g['number_of_runs'])
+    capi.lib().xrt_last_path(1)
+    dev = xrt.DeviceTrace(flat)
+    dev.trace(seeds, g['number_of_iter'], keep_images=True)
+    meta, image = dev.results()
+    for nm in flat.names:
+        assert int(meta[nm]['num_out']) == int(gold['num_out/' + nm]), nm
+    for nm in flat.names[1:]:
+        if image[nm] is not None:
+            assert np.array_equal(image[nm].astype(np.int64), gold['image/' + nm]), nm
+    path = capi.lib().xrt_last_path(1)
+    assert bool(path & capi.PATH_MESH_SPLIT) == (route != 'fused'), (path, route)
+
+
+@pytest.mark.gpu
 def test_few_long_runs_are_segmented_and_equal_the_oracle():
     """3 runs x 3e6 rays x 2 iterations of the bench scene: the library segments them on its own;
     counts and both images equal the oracle's, and the next iteration continues the right streams."""

@@ -121,9 +121,10 @@ struct KMesh {               // device pointers, see xrt_mesh_t
     const double* plane_rec;        // [n_first + 1][16] plane form of the same faces: n, n.p0, U, u0, V, v0, n.n (+inf: degenerate)
     const XRT_G1 d4v* face_rec;     // [n_faces] KFaceRec, read as four 32-byte vectors
     gip point_faces;                // [n_points][8] the faces around a point, -1 where the reference's mask is False
-    gip ct_simplices, ct_neighbors;
-    const XRT_G1 d4v* ct_srec;      // [n_simplices] 96 bytes: the three vertices, the edge vectors e12, e23, e31, the neighbour weights g (ct_shared)
-    gdp ct_transform, ct_points, ct_values, ct_grad;
+    // the Clough-Tocher tables, one cache line per simplex / vertex and use:
+    const XRT_G1 d4v* ct_srec;      // [n_simplices][16] the three vertices, the edge vectors e12, e23, e31, the neighbour weights g (ct_shared)
+    gdp ct_frec;                    // [n_simplices][8] barycentric transform (6) and the three neighbours (ct_find_simplex)
+    gdp ct_vrec;                    // [n_points][16] value, d/dx, d/dy of z, normal_x, normal_y, normal_z at a vertex (ct_eval)
     gip ct_vertex_simplex;
     // x-y bucket grid over the points for the exact nearest-point search (built by the library)
     int32_t grid_nx, grid_ny;
@@ -2808,7 +2809,7 @@ static size_t mesh_bytes(const xrt_mesh_t* m)
     const size_t P = (size_t)m->n_points, F = (size_t)m->n_faces, Cn = (size_t)m->n_coarse_faces, T = (size_t)m->n_simplices;
     const size_t n_first = Cn > 0 ? Cn : F;
     b += al256(F * 24) + al256((n_first + 1) * 80) + al256((n_first + 1) * 128) + al256(F * sizeof(KFaceRec)) + al256(P * 32) + al256(P * 24);
-    if (m->interpolate) b += 2 * al256(T * 3 * 4) + al256(T * 6 * 8) + al256(P * 2 * 8) + al256(4 * P * 8) + al256(8 * P * 8) + al256(P * 4) + al256(T * 96);
+    if (m->interpolate) b += al256(T * 128) + al256(T * 64) + al256(P * 128) + al256(P * 4);
     b += al256((2 * P + 1) * sizeof(KCellRec));                       // bucket grid: <= P buckets + <= P chained points
     b += al256((64 * 64 + 1) * 4) + al256(n_first * 16 * 4 + 64) + al256(64 * 64 * 16);   // face grid of the first pass: cell starts, lists (<= 16 cells per face on average), cell slabs
     b += al256((n_first + 1) * 96);                                   // point-source form of the first pass
@@ -3662,21 +3663,31 @@ static int upload_meshes(const xrt_scene_t* sc, char* ws, int n_runs, KScene* ks
         }
         k.points = (gdp)put(m->points, P * 24);
         if (m->interpolate) {
-            k.ct_simplices = (gip)put(m->ct_simplices, T * 12);
-            k.ct_neighbors = (gip)put(m->ct_neighbors, T * 12);
-            k.ct_transform = (gdp)put(m->ct_transform, T * 48);
-            k.ct_points = (gdp)put(m->ct_points, P * 16);
-            k.ct_values = (gdp)put(m->ct_values, 4 * P * 8);
-            k.ct_grad = (gdp)put(m->ct_grad, 8 * P * 8);
             k.ct_vertex_simplex = (gip)put(m->ct_vertex_simplex, P * 4);
+            {
+                std::vector<double> fr(T * 8, 0.0), vr(P * 16, 0.0);
+                for (size_t si = 0; si < T; si++) {
+                    for (int c = 0; c < 6; c++) fr[8 * si + c] = m->ct_transform[6 * si + c];
+                    const int32_t nb4[4] = {m->ct_neighbors[3 * si], m->ct_neighbors[3 * si + 1], m->ct_neighbors[3 * si + 2], 0};
+                    memcpy(&fr[8 * si + 6], nb4, 16);
+                }
+                for (size_t pi = 0; pi < P; pi++)
+                    for (int wq = 0; wq < 4; wq++) {
+                        vr[16 * pi + 3 * wq] = m->ct_values[(size_t)wq * P + pi];
+                        vr[16 * pi + 3 * wq + 1] = m->ct_grad[((size_t)wq * P + pi) * 2];
+                        vr[16 * pi + 3 * wq + 2] = m->ct_grad[((size_t)wq * P + pi) * 2 + 1];
+                    }
+                k.ct_frec = (gdp)put(fr.data(), fr.size() * 8);
+                k.ct_vrec = (gdp)put(vr.data(), vr.size() * 8);
+            }
             // per simplex what the evaluation needs of it alone (SciPy _clough_tocher_2d_single: the edge vectors and, per
             // neighbour, the weight g from the neighbour's centroid in this simplex' barycentric coordinates), with the
             // operations ct_shared used to make per ray (this file is compiled without contraction, host and device)
-            std::vector<double> sr(T * 12, 0.0);
+            std::vector<double> sr(T * 16, 0.0);
             for (size_t si = 0; si < T; si++) {
                 const int32_t* v = m->ct_simplices + 3 * si;
                 const double* pts = m->ct_points;
-                double* o = &sr[12 * si];
+                double* o = &sr[16 * si];
                 int32_t iv[4] = {v[0], v[1], v[2], 0};
                 memcpy(o, iv, 16);
                 o[2] = pts[2 * v[1]] - pts[2 * v[0]]; o[3] = pts[2 * v[1] + 1] - pts[2 * v[0] + 1];
@@ -4678,6 +4689,11 @@ __global__ void xrt_selftest_div3_kernel(const double* num, const double* den, i
     int c = (__double_as_longlong(q.x) != __double_as_longlong(r0) && !(q.x != q.x && r0 != r0))
           + (__double_as_longlong(q.y) != __double_as_longlong(r1) && !(q.y != q.y && r1 != r1))
           + (__double_as_longlong(q.z) != __double_as_longlong(r2) && !(q.z != q.z && r2 != r2));
+    // ... and of ct_div3 (xrt_mesh.inc) against / 3 on the same operands
+    const double t0 = ct_div3_checked(v.x), t1 = ct_div3_checked(v.y), t2 = ct_div3_checked(m), u0 = v.x / 3, u1 = v.y / 3, u2 = m / 3;
+    c += (__double_as_longlong(t0) != __double_as_longlong(u0) && !(t0 != t0 && u0 != u0))
+       + (__double_as_longlong(t1) != __double_as_longlong(u1) && !(t1 != t1 && u1 != u1))
+       + (__double_as_longlong(t2) != __double_as_longlong(u2) && !(t2 != t2 && u2 != u2));
     if (c) atomicAdd(bad, (unsigned long long)c);
 }
 
