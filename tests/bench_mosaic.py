@@ -8,7 +8,7 @@ runs = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 rays = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000
 config = bench.spectrometer_config(rays, runs, seed=5)
 config['optics']['crystal'].update(class_name='XicsrtOpticSphericalMosaicCrystal', mosaic_spread=float(np.radians(0.4)),
-                                   mosaic_depth=15, rocking_fwhm=2e-3)
+                                   mosaic_depth=int(os.environ.get('MOSAIC_DEPTH', '15')), rocking_fwhm=2e-3)
 config = xconfig.get_config(config)
 flat = xrt.Elements(config).flatten()
 seeds = xrt.run_seeds(5, runs)

@@ -1,0 +1,19 @@
+"""Development: per-step clocks of the mosaic layers (library built with -DXRT_ST_CLOCKS=1). Not a test."""
+import sys, os, time, json
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch, bench
+from xicsrt_amd import xicsrt_raytrace as xrt, config as xconfig
+runs = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+rays = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000
+config = bench.spectrometer_config(rays, runs, seed=5)
+config['optics']['crystal'].update(class_name='XicsrtOpticSphericalMosaicCrystal', mosaic_spread=float(np.radians(0.4)), mosaic_depth=15, rocking_fwhm=2e-3)
+config = xconfig.get_config(config)
+flat = xrt.Elements(config).flatten()
+seeds = xrt.run_seeds(5, runs)
+dev = xrt.DeviceTrace(flat)
+dev.trace(seeds, 1); dev.results()
+t0 = time.time(); dev.trace(seeds, 1); dev.results(); dt = time.time() - t0
+w = dev._ws[128:160].cpu().numpy().view(np.uint64)
+print(json.dumps({'runs': runs, 'call_ms': dt * 1e3, 'gauss_ms_per_wg': float(w[0]) / 1e5 / runs, 'uniform_ms_per_wg': float(w[1]) / 1e5 / runs,
+                  'pass_ms_per_wg': float(w[2]) / 1e5 / runs, 'ray_layers': int(w[3])}))

@@ -125,6 +125,7 @@ struct KMesh {               // device pointers, see xrt_mesh_t
     const XRT_G1 d4v* ct_srec;      // [n_simplices][16] the three vertices, the edge vectors e12, e23, e31, the neighbour weights g (ct_shared)
     gdp ct_frec;                    // [n_simplices][8] barycentric transform (6) and the three neighbours (ct_find_simplex)
     gdp ct_vrec;                    // [n_points][16] value, d/dx, d/dy of z, normal_x, normal_y, normal_z at a vertex (ct_eval)
+    gip face_simplex;               // [n_faces] the simplex with a face's three vertices, -1: none (where the walk starts; null: not built)
     gip ct_vertex_simplex;
     // x-y bucket grid over the points for the exact nearest-point search (built by the library)
     int32_t grid_nx, grid_ny;
@@ -2439,7 +2440,7 @@ void xrt_mesh_rest_kernel(const KScene* __restrict__ scene_g, const KArgs args, 
         CtShared G;
         int idx = -1;
         MeshHit h = mesh_rest_impl<false>(op.mesh, c[0 * 256], c[1 * 256], c[2 * 256], c[3 * 256], c[4 * 256], c[5 * 256], face, &idx);
-        if constexpr (CT) { if (h.hit != 0) mesh_rest_ct(op.mesh, idx, h, G); }
+        if constexpr (CT) { if (h.hit != 0) mesh_rest_ct(op.mesh, idx, h.aux, h, G); }
         V3 X;
         X.x = h.x; X.y = h.y; X.z = h.z;
         alive = (h.hit != 0) && check_bounds<true>(op, X);
@@ -2527,6 +2528,7 @@ void xrt_mesh_rest_lds_kernel(const KScene* __restrict__ scene_g, const KArgs ar
                 if (h.hit != 0) {
                     c[0 * 256] = X.x; c[1 * 256] = X.y; c[2 * 256] = X.z;
                     c[6 * 256] = __hiloint2double(0, idx);
+                    args.cand_aux[crun + (size_t)i] = (uint32_t)h.aux;          // (the face that was hit: where the interpolation's walk starts)
                 } else args.cand_aux[crun + (size_t)i] = XRT_CAND_DEAD;
             } else {
                 alive = (h.hit != 0) && check_bounds<true>(op, X);
@@ -2569,14 +2571,16 @@ void xrt_mesh_ct_kernel(const KScene* __restrict__ scene_g, const KArgs args, in
     const size_t crun = (size_t)run * (size_t)args.cand_cap;
     const int64_t i = ray_lo + (int64_t)(256u * blk + (uint32_t)threadIdx.x);
     double* c = args.cand + crun * (size_t)q_ncomp + (i >> 8) * (int64_t)(q_ncomp * 256) + (i & 255);
-    const bool have = 256u * blk + (uint32_t)threadIdx.x < n_unit && args.cand_aux[crun + (size_t)i] != XRT_CAND_DEAD;
+    uint32_t face = XRT_CAND_DEAD;
+    if (256u * blk + (uint32_t)threadIdx.x < n_unit) face = args.cand_aux[crun + (size_t)i];
+    const bool have = face != XRT_CAND_DEAD;
     const KOptic& op = SC.opt[be];
     bool alive = false;
     if (have) {
         MeshHit h;
         h.x = c[0 * 256]; h.y = c[1 * 256]; h.z = c[2 * 256]; h.aux = 0; h.hit = 1;
         CtShared G;
-        mesh_rest_ct(op.mesh, __double2loint(c[6 * 256]), h, G);
+        mesh_rest_ct(op.mesh, __double2loint(c[6 * 256]), (int)face, h, G);
         V3 X;
         X.x = h.x; X.y = h.y; X.z = h.z;
         alive = check_bounds<true>(op, X);
@@ -2790,7 +2794,7 @@ static bool needs_staged(const xrt_scene_t* sc)
 // Staged path: one workgroup per slot, one per CU (XRT_ST_SLOTS = 256 CUs), fewer when the per-slot
 // ray arrays of a scene would take more than XRT_ST_BUDGET bytes of workspace in total.
 #define XRT_ST_SLOTS 256
-#define XRT_ST_BUDGET (64ull << 30)
+#define XRT_ST_BUDGET (96ull << 30)
 static int staged_slots_for(int n_runs, size_t per_slot_bytes, int per_cu)
 {
     size_t s = (size_t)XRT_ST_SLOTS * (size_t)per_cu;
@@ -2809,7 +2813,7 @@ static size_t mesh_bytes(const xrt_mesh_t* m)
     const size_t P = (size_t)m->n_points, F = (size_t)m->n_faces, Cn = (size_t)m->n_coarse_faces, T = (size_t)m->n_simplices;
     const size_t n_first = Cn > 0 ? Cn : F;
     b += al256(F * 24) + al256((n_first + 1) * 80) + al256((n_first + 1) * 128) + al256(F * sizeof(KFaceRec)) + al256(P * 32) + al256(P * 24);
-    if (m->interpolate) b += al256(T * 128) + al256(T * 64) + al256(P * 128) + al256(P * 4);
+    if (m->interpolate) b += al256(T * 128) + al256(T * 64) + al256(P * 128) + al256(P * 4) + al256(F * 4);
     b += al256((2 * P + 1) * sizeof(KCellRec));                       // bucket grid: <= P buckets + <= P chained points
     b += al256((64 * 64 + 1) * 4) + al256(n_first * 16 * 4 + 64) + al256(64 * 64 * 16);   // face grid of the first pass: cell starts, lists (<= 16 cells per face on average), cell slabs
     b += al256((n_first + 1) * 96);                                   // point-source form of the first pass
@@ -3680,6 +3684,33 @@ static int upload_meshes(const xrt_scene_t* sc, char* ws, int n_runs, KScene* ks
                 k.ct_frec = (gdp)put(fr.data(), fr.size() * 8);
                 k.ct_vrec = (gdp)put(vr.data(), vr.size() * 8);
             }
+            {   // where the walk to a hit point's simplex starts: at the simplex that has the hit face's vertices (the faces
+                // are the reference's Delaunay triangles of the same points), if there is one
+                struct Key3 { uint64_t a, b, c; bool operator==(const Key3& o) const { return a == o.a && b == o.b && c == o.c; } };
+                struct Key3Hash { size_t operator()(const Key3& q) const { return (size_t)(q.a * 0x9e3779b97f4a7c15ull ^ (q.b + 0x7f4a7c15ull) * 0xbf58476d1ce4e5b9ull ^ (q.c * 0x94d049bb133111ebull)); } };
+                std::unordered_map<Key3, int32_t, Key3Hash> pt_of, simplex_of;
+                pt_of.reserve(P * 2);
+                auto key_of = [](const double* v) { Key3 q; memcpy(&q.a, v, 8); memcpy(&q.b, v + 1, 8); memcpy(&q.c, v + 2, 8); return q; };
+                for (size_t i = 0; i < P; i++) pt_of.emplace(key_of(m->points + 3 * i), (int32_t)i);
+                auto sorted3 = [](uint64_t a, uint64_t b, uint64_t c) { Key3 q; if (a > b) std::swap(a, b); if (b > c) std::swap(b, c); if (a > b) std::swap(a, b); q.a = a; q.b = b; q.c = c; return q; };
+                simplex_of.reserve(T * 2);
+                for (size_t si = 0; si < T; si++)
+                    simplex_of.emplace(sorted3((uint64_t)m->ct_simplices[3 * si], (uint64_t)m->ct_simplices[3 * si + 1], (uint64_t)m->ct_simplices[3 * si + 2]), (int32_t)si);
+                std::vector<int32_t> fs(F, -1);
+                for (size_t i = 0; i < F; i++) {
+                    const double* vs[3] = {m->p0 + 3 * i, m->p1 + 3 * i, m->p2 + 3 * i};
+                    uint64_t pi[3];
+                    bool all = true;
+                    for (int j = 0; j < 3 && all; j++) {
+                        const auto it = pt_of.find(key_of(vs[j]));
+                        if (it == pt_of.end()) all = false; else pi[j] = (uint64_t)it->second;
+                    }
+                    if (!all) continue;
+                    const auto it = simplex_of.find(sorted3(pi[0], pi[1], pi[2]));
+                    if (it != simplex_of.end()) fs[i] = it->second;
+                }
+                k.face_simplex = (gip)put(fs.data(), F * 4);
+            }
             // per simplex what the evaluation needs of it alone (SciPy _clough_tocher_2d_single: the edge vectors and, per
             // neighbour, the weight g from the neighbour's centroid in this simplex' barycentric coordinates), with the
             // operations ct_shared used to make per ray (this file is compiled without contraction, host and device)
@@ -4029,26 +4060,32 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
             HIP_TRY(hipEventRecord(timing_ev[ti][0], stream));
         }
         const int src = sc->source.kind == XRT_SRC_PLASMA ? 1 : (sc->source.kind == XRT_SRC_EXTERNAL ? 2 : 0);
-        bool special = false;
-        for (int e = 0; e < sc->n_optics; e++)
+        bool special = false, has_mesh = false;
+        for (int e = 0; e < sc->n_optics; e++) {
             special = special || sc->optics[e].interact == XRT_INTERACT_MOSAIC || sc->optics[e].shape == XRT_SHAPE_MESH ||
                       (sc->optics[e].flags & XRT_F_TRACE_LOCAL);
+            has_mesh = has_mesh || sc->optics[e].shape == XRT_SHAPE_MESH;
+        }
         if (src == 2 && !hist) return fail(-2, "%s", "external rays are traced through xrt_trace_history");
         g_paths |= XRT_PATH_STAGED;
         if (src != 2 && !hist && !env_on("XICSRT_NO_STAGE_SPLIT")) {
             g_paths |= XRT_PATH_STAGE_SPLIT;
             // source and optics in separate launches, a batch of `slots` runs at a time
             g.n_src_slot = reinterpret_cast<int64_t*>(g.bundle_off + (size_t)slots * XRT_ST_BUNDLE_ROWS * (size_t)(sc->source.bundle_count > 0 ? sc->source.bundle_count : 0));
-            void (*k1)(const KScene*, const KArgs, const KStaged) = src == 1 ? xrt_staged_kernel<false, 1, false, 1>
-                                                                            : xrt_staged_kernel<false, 0, false, 1>;
+            void (*k1)(const KScene*, const KArgs, const KStaged) = src == 1 ? xrt_staged_kernel<false, 1, 0, 1>
+                                                                            : xrt_staged_kernel<false, 0, 0, 1>;
+            // (the optics stage without the mesh code -- mosaic crystals, local frames -- needs half the registers of the one with it)
             void (*k2)(const KScene*, const KArgs, const KStaged) =
-                src == 1 ? (special ? xrt_staged_kernel<false, 1, true, 2> : xrt_staged_kernel<false, 1, false, 2>)
-                         : (special ? xrt_staged_kernel<false, 0, true, 2> : xrt_staged_kernel<false, 0, false, 2>);
-            for (int base_run = 0; base_run < n_runs; base_run += slots) {
-                const int nb = (n_runs - base_run) < slots ? (n_runs - base_run) : slots;
+                src == 1 ? (has_mesh ? xrt_staged_kernel<false, 1, 2, 2> : special ? xrt_staged_kernel<false, 1, 1, 2> : xrt_staged_kernel<false, 1, 0, 2>)
+                         : (has_mesh ? xrt_staged_kernel<false, 0, 2, 2> : special ? xrt_staged_kernel<false, 0, 1, 2> : xrt_staged_kernel<false, 0, 0, 2>);
+            // (batches of equal size: a workgroup's time hardly depends on how many share its CU -- the stages are chains
+            //  of barriers and memory round trips -- so a last batch of a few runs would cost as much as a full one)
+            const int n_batches = (n_runs + slots - 1) / slots, per_batch = (n_runs + n_batches - 1) / n_batches;
+            for (int base_run = 0; base_run < n_runs; base_run += per_batch) {
+                const int nb = (n_runs - base_run) < per_batch ? (n_runs - base_run) : per_batch;
                 g.run_base = base_run;
                 a.n_runs = nb;
-                const int g1 = src == 1 ? 768 : 1024, g2 = special ? 512 : 768;     // workgroups per launch: 3-4 (source) and 3 or 1 (optics) per CU
+                const int g1 = src == 1 ? 768 : 1024, g2 = has_mesh ? 512 : (special ? 1024 : 768);     // workgroups per launch: 3-4 (source) and 2 - 4 (optics) per CU
                 int grid1 = nb < g1 ? nb : g1, grid2 = nb < g2 ? nb : g2;
                 HIP_TRY(hipMemsetAsync(ws, 0, 64, stream));
                 hipLaunchKernelGGL(k1, dim3(grid1), dim3(XRT_TILE), lds, stream, device_scene(ws), a, g);
@@ -4061,11 +4098,11 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
             return 0;
         }
         void (*kern)(const KScene*, const KArgs, const KStaged);
-        if (hist) kern = src == 2 ? (special ? xrt_staged_kernel<true, 2, true> : xrt_staged_kernel<true, 2, false>)
-                       : src == 1 ? (special ? xrt_staged_kernel<true, 1, true> : xrt_staged_kernel<true, 1, false>)
-                                  : (special ? xrt_staged_kernel<true, 0, true> : xrt_staged_kernel<true, 0, false>);
-        else      kern = src == 1 ? (special ? xrt_staged_kernel<false, 1, true> : xrt_staged_kernel<false, 1, false>)
-                                  : (special ? xrt_staged_kernel<false, 0, true> : xrt_staged_kernel<false, 0, false>);
+        if (hist) kern = src == 2 ? (special ? xrt_staged_kernel<true, 2, 2> : xrt_staged_kernel<true, 2, 0>)
+                       : src == 1 ? (special ? xrt_staged_kernel<true, 1, 2> : xrt_staged_kernel<true, 1, 0>)
+                                  : (special ? xrt_staged_kernel<true, 0, 2> : xrt_staged_kernel<true, 0, 0>);
+        else      kern = src == 1 ? (special ? xrt_staged_kernel<false, 1, 2> : xrt_staged_kernel<false, 1, 0>)
+                                  : (special ? xrt_staged_kernel<false, 0, 2> : xrt_staged_kernel<false, 0, 0>);
         hipLaunchKernelGGL(kern, dim3(slots), dim3(XRT_TILE), lds, stream, device_scene(ws), a, g);
         HIP_TRY(hipGetLastError());
         if (ti >= 0) HIP_TRY(hipEventRecord(timing_ev[ti][1], stream));
