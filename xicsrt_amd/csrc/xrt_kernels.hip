@@ -3920,7 +3920,7 @@ template <bool HIST, int VARIANT, int SEG = 0>
 static int launch_variant(const KScene* ks, const KArgs& a_in, int n_runs, size_t lds, hipStream_t stream, bool may_leave_tail = false)
 {
     KArgs a = a_in;
-    if (a.image_rep > 1u && a.images) a.images = a.images_rep;      // (the staged kernels add into the caller's bins)
+    if (a.image_rep > 1u && a.images) a.images = a.images_rep;
 #ifdef XRT_DEV_ONLY_LEAN     // development builds: only the lean kernels (-DXRT_DEV_VARIANT=2: the mesh / local-frame ones) are compiled
 #ifndef XRT_DEV_VARIANT
 #define XRT_DEV_VARIANT 0
@@ -4050,6 +4050,7 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
         g.spatial_gaussian = sc->source.spatial_dist == XRT_SPATIAL_GAUSSIAN;
         a.streams = streams; a.heads = heads; a.n_runs = n_runs; a.n_src_heads = nh;
         a.run_counter = reinterpret_cast<uint32_t*>(ws);
+        if (a.image_rep > 1u && a.images) a.images = a.images_rep;      // (the replicas of the bins, summed behind the call's last launch)
         HIP_TRY(hipMemsetAsync(ws, 0, 64, stream));
         const size_t lds = sizeof(double) * XRT_TILE_COMP * XRT_TILE + sizeof(uint32_t) * (2 * XRT_TILE + XRT_RING + 16 + 2 * (XRT_DEV_MAX_OPTICS + 2) + 16);
         int ti = -1;
