@@ -246,8 +246,11 @@ class DeviceTrace:
         capi.check(self.lib.xrt_scene_check(flat.byref()), 'xrt_scene_check')
         t = self.torch
         self.dev = t.device('cuda', t.cuda.current_device())
-        self.num_out = t.zeros(flat.n_elements, dtype=t.int64, device=self.dev)
-        self.images = t.zeros(max(flat.image_bins, 1), dtype=t.int64, device=self.dev)
+        # counters and pixel bins are two views of one buffer: the results come over in one copy
+        self._acc = t.zeros(flat.n_elements + max(flat.image_bins, 1), dtype=t.int64, device=self.dev)
+        self.num_out = self._acc[:flat.n_elements]
+        self.images = self._acc[flat.n_elements:]
+        self._acc_host = None
         self._ws = None
 
     def _workspace(self, n_runs):
@@ -330,9 +333,23 @@ class DeviceTrace:
 
     def results(self):
         """Host copies (synchronises the stream): num_out list, {optic: image or None}."""
-        self.raise_status()
-        self.torch.cuda.current_stream().synchronize()
-        return self.unpack(self.num_out.cpu().numpy(), self.images.cpu().numpy())
+        t = self.torch
+        if self._ws is None:
+            t.cuda.current_stream().synchronize()
+            host = self._acc.cpu().numpy()
+            return self.unpack(host[:self.flat.n_elements], host[self.flat.n_elements:])
+        # the status word and the results are queued behind the launches as two copies into pinned memory and waited for
+        # once (three blocking copies cost three round trips: a quarter of a small call)
+        if self._acc_host is None:
+            self._acc_host = t.empty(self._acc.numel(), dtype=t.int64, pin_memory=True)
+            self._flags_host = t.empty(4, dtype=t.uint8, pin_memory=True)
+        self._flags_host.copy_(self._ws[64:68], non_blocking=True)
+        self._acc_host.copy_(self._acc, non_blocking=True)
+        t.cuda.current_stream().synchronize()
+        if int(self._flags_host.view(t.int32)[0]) != 0:
+            self.raise_status()             # (the library words the condition: xrt_check)
+        host = self._acc_host.numpy().copy()
+        return self.unpack(host[:self.flat.n_elements], host[self.flat.n_elements:])
 
     def unpack(self, num_out, images):
         meta = {}
