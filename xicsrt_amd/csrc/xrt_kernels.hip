@@ -188,7 +188,8 @@ struct KOptic {
     double  scr2_tail, inv_two_d;               // bound on p for |sin(inc - bragg)| >= 0.01; 1 / (2 d)
     int32_t scr2_ok;
     int32_t mesh_lds_bytes;             // host side: KMesh.lds_bytes of `mesh` (which launch finishes a split mesh intersection)
-    int32_t mesh_dir_bytes, pad4;       // host side: LDS bytes of the mesh's direction grid (KMesh.dg_n), 0: none
+    int32_t mesh_dir_bytes;             // host side: LDS bytes of the mesh's direction grid (KMesh.dg_n), 0: none
+    int32_t mesh_ct_lds_bytes;          // host side: bytes of the mesh's Clough-Tocher vertex table when it fits the LDS (xrt_mesh_ct_lds_kernel), else 0
 };
 
 struct KScene {
@@ -2598,6 +2599,72 @@ void xrt_mesh_ct_kernel(const KScene* __restrict__ scene_g, const KArgs args, in
     }
 }
 
+// The same with the vertex table (value and gradient of height and normal components: 96 bytes per point) in LDS, for a
+// mesh whose table fits (41 x 41 points: 161 376 of the 163 840 bytes): 24 of a ray's ~40 gathers then cost an LDS read
+// instead of an L1 tag lookup per lane.  One 1024-thread workgroup per CU, blocks of 1024 parked rays round robin.
+__global__ __launch_bounds__(XRT_MESH_LDS_THREADS)
+void xrt_mesh_ct_lds_kernel(const KScene* __restrict__ scene_g, const KArgs args, int be, uint32_t blocks_per_unit, uint32_t n_units)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const KScene* scl = scene_fresh(scene_g);
+    const KOptic& op = SC.opt[be];
+    const KMesh* Mp = op.mesh;
+    MeshRef M = *(const XRT_C4 KMesh*)uniform_u64((uint64_t)Mp);
+    const int tid = threadIdx.x;
+    double* l_v = reinterpret_cast<double*>(lds_raw);                       // [n_points][12]
+    {
+        const uint32_t np = (uint32_t)M.n_points;
+        const gdp g = M.ct_vrec;
+        for (uint32_t i = (uint32_t)tid; i < 12u * np; i += XRT_MESH_LDS_THREADS) { const uint32_t v = i / 12u; l_v[i] = g[16u * v + (i - 12u * v)]; }
+    }
+    __syncthreads();
+    const XRT_LDS3 double* lv = (const XRT_LDS3 double*)l_v;
+    const int64_t N = SRC.n_rays;
+    const bool q_has_wl = !(SRC.wavelength_dist == XRT_WL_CONST && !SRC.has_velocity);
+    const int q_ncomp = 9 + (q_has_wl ? 1 : 0);
+    const uint32_t upr = (uint32_t)args.n_seg * (uint32_t)args.n_sub;
+    const uint64_t items = (uint64_t)n_units * blocks_per_unit;
+    for (uint64_t it = blockIdx.x; it < items; it += gridDim.x) {
+        const uint32_t unit = (uint32_t)(it / blocks_per_unit), blk = (uint32_t)(it - (uint64_t)unit * blocks_per_unit);
+        const uint32_t n_unit = uni32(args.unit_flag[unit]) - 1u;
+        if (1024u * blk >= n_unit) continue;
+        const uint32_t run = unit / upr, uidx = unit - run * upr;
+        const uint32_t seg = uidx / (uint32_t)args.n_sub, sub = uidx - seg * (uint32_t)args.n_sub;
+        const int64_t seg_lo = (int64_t)seg * args.seg_len;
+        const int64_t seg_hi = (seg_lo + args.seg_len < N) ? seg_lo + args.seg_len : N;
+        int64_t ray_lo = seg_lo + (int64_t)sub * args.sub_len;
+        if (ray_lo > seg_hi) ray_lo = seg_hi;
+        const size_t crun = (size_t)run * (size_t)args.cand_cap;
+        const uint32_t k = 1024u * blk + (uint32_t)tid;
+        const int64_t i = ray_lo + (int64_t)k;
+        double* c = args.cand + crun * (size_t)q_ncomp + (i >> 8) * (int64_t)(q_ncomp * 256) + (i & 255);
+        uint32_t face = XRT_CAND_DEAD;
+        if (k < n_unit) face = args.cand_aux[crun + (size_t)i];
+        const bool have = face != XRT_CAND_DEAD;
+        bool alive = false;
+        if (have) {
+            MeshHit h;
+            h.x = c[0 * 256]; h.y = c[1 * 256]; h.z = c[2 * 256]; h.aux = 0; h.hit = 1;
+            CtShared G;
+            mesh_rest_ct_at(Mp, lv, 12, __double2loint(c[6 * 256]), (int)face, h, G);
+            V3 X;
+            X.x = h.x; X.y = h.y; X.z = h.z;
+            alive = check_bounds<true>(op, X);
+            if (alive) {
+                const V3 nrm = mesh_normal_kept_at(lv, 12, G, h.aux);
+                c[2 * 256] = X.z;
+                c[6 * 256] = nrm.x; c[7 * 256] = nrm.y; c[8 * 256] = nrm.z;
+            } else args.cand_aux[crun + (size_t)i] = XRT_CAND_DEAD;
+        }
+        const unsigned long long ab = __ballot(alive);
+        if ((tid & 63) == 0 && 64u * (k >> 6) < ((n_unit + 63u) & ~63u)) {
+            const uint32_t n = (uint32_t)__popcll(ab);
+            args.batch_alive[((crun + (size_t)ray_lo) >> 6) + (k >> 6)] = n;
+            if (n) atomicAdd(&args.unit_alive[unit], n);
+        }
+    }
+}
+
 #undef SC
 #undef SRC
 
@@ -3357,6 +3424,7 @@ static int upload_meshes(const xrt_scene_t* sc, char* ws, int n_runs, KScene* ks
         ks->opt[e].mesh = nullptr;
         ks->opt[e].mesh_lds_bytes = 0;
         ks->opt[e].mesh_dir_bytes = 0;
+        ks->opt[e].mesh_ct_lds_bytes = 0;
         if (sc->optics[e].shape != XRT_SHAPE_MESH) continue;
         // The packed tables are host temporaries, copied synchronously; an earlier call on `stream` may still be
         // reading this part of the workspace (with another layout): wait for it first.  (Mesh scenes only; every other
@@ -3822,6 +3890,8 @@ static int upload_meshes(const xrt_scene_t* sc, char* ws, int n_runs, KScene* ks
         HIP_TRY(hipMemcpy(base, &k, sizeof(KMesh), hipMemcpyHostToDevice));
         ks->opt[e].mesh = reinterpret_cast<const KMesh*>(base);
         ks->opt[e].mesh_lds_bytes = k.lds_bytes;
+        ks->opt[e].mesh_ct_lds_bytes = (m->interpolate && (size_t)m->n_points * 96 + 64 <= 160u * 1024u && !env_on("XICSRT_NO_MESH_LDS"))
+                                           ? (int32_t)((size_t)m->n_points * 96) : 0;
         ks->opt[e].mesh_dir_bytes = k.dg_n > 0 ? (int32_t)(((size_t)k.n_first + 1) * 96 + (size_t)k.dg_n * k.dg_n * 8) : 0;
         base += mesh_bytes(m);
     }
@@ -4342,6 +4412,11 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
                     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(xrt_mesh_rest_lds_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_m));
                     hipLaunchKernelGGL((xrt_mesh_rest_lds_kernel<true>), dim3(grid), dim3(XRT_MESH_LDS_THREADS), (size_t)lds_m, stream, device_scene(ws), am, be, bpu4, (uint32_t)(n_runs * S * M));
                     HIP_TRY(hipGetLastError());
+                    const int lds_ct = ks.opt[be].mesh_ct_lds_bytes;
+                    if (lds_ct > 0) {
+                        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(xrt_mesh_ct_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_ct));
+                        hipLaunchKernelGGL(xrt_mesh_ct_lds_kernel, dim3(grid), dim3(XRT_MESH_LDS_THREADS), (size_t)lds_ct, stream, device_scene(ws), am, be, bpu4, (uint32_t)(n_runs * S * M));
+                    } else
                     hipLaunchKernelGGL(xrt_mesh_ct_kernel, dim3((unsigned)blocks), dim3(XRT_TILE), 0, stream, device_scene(ws), am, be, bpu);
                 } else {
                     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(xrt_mesh_rest_lds_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_m));
