@@ -148,9 +148,9 @@ struct KMesh {               // device pointers, see xrt_mesh_t
     // over the faces' images lists the <= 8 faces whose image (with a margin) touches it, ascending; 0xff: no
     // further face, a first byte of 0xfe: more than eight (the ray walks every face).  The first phase of a split launch
     // keeps the cells and pt_rec in LDS.
-    int32_t dg_n, dg_pad;
+    int32_t dg_n, dg_big;           // dg_big: 254 faces or more -- 16-bit face numbers (four words per cell, 0xffff / 0xfffe), tables read from global memory
     double  dg_x0, dg_y0, dg_ihx, dg_ihy, dg_ex[3], dg_ey[3], dg_ez[3];
-    const uint32_t* dg_cells;       // [dg_n * dg_n][2]: eight face numbers
+    const uint32_t* dg_cells;       // [dg_n * dg_n][2 or 4]: eight face numbers
     // plane form of EVERY face (as plane_rec) for the second pass around the nearest point; [13]: how far outside (in
     // barycentric units) a point must lie for the reference's area test (diff < 1e-10) to fail for sure
     const XRT_G1 d4v* plane2_rec;   // [n_faces][16] or null (no second pass)
@@ -1596,7 +1596,7 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
                                         by_grid = true;
                                     }
                                 }
-                                if (!by_grid) aux = mesh_first(op.mesh, ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z);
+                                if (!by_grid) aux = mesh_first(op.mesh, ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z);      // (many faces: through the direction grid in global memory, if there is one)
                                 hit = aux >= 0;
                                 X = ray.o;
                                 alive = hit;
@@ -2411,8 +2411,10 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
 // ShapeMesh.intersect (optics/_ShapeMesh.py:289-432 behind the first pass: hit point of the face, nearest fine point, the
 // <= 8 faces around it, interpolation), the bounds and the normal for every ray the first phase parked, a thread per ray.
 // Nothing here depends on a neighbour or on a stream: the grid is (unit, block of 256 of its rays), the registers are
-// those of the mesh code alone (CT = false: a mesh without interpolation, no Clough-Tocher code).
-template <bool CT>
+// those of the mesh code alone.  DEFER (an interpolated mesh): only up to the hit face; the hit point, the nearest point's
+// index (in the slot of the normal's first component) and the face are left for xrt_mesh_ct_kernel / xrt_mesh_ct_lds_kernel,
+// which interpolate, check the bounds and count.
+template <bool DEFER>
 __global__ __launch_bounds__(XRT_TILE)
 void xrt_mesh_rest_kernel(const KScene* __restrict__ scene_g, const KArgs args, int be, uint32_t blocks_per_unit)
 {
@@ -2438,21 +2440,26 @@ void xrt_mesh_rest_kernel(const KScene* __restrict__ scene_g, const KArgs args, 
     bool alive = false;
     if (have) {
         const int face = (int)args.cand_aux[crun + (size_t)i];
-        CtShared G;
         int idx = -1;
-        MeshHit h = mesh_rest_impl<false>(op.mesh, c[0 * 256], c[1 * 256], c[2 * 256], c[3 * 256], c[4 * 256], c[5 * 256], face, &idx);
-        if constexpr (CT) { if (h.hit != 0) mesh_rest_ct(op.mesh, idx, h.aux, h, G); }
+        const MeshHit h = mesh_rest_impl<false>(op.mesh, c[0 * 256], c[1 * 256], c[2 * 256], c[3 * 256], c[4 * 256], c[5 * 256], face, &idx);
         V3 X;
         X.x = h.x; X.y = h.y; X.z = h.z;
-        alive = (h.hit != 0) && check_bounds<true>(op, X);
-        if (alive) {
-            V3 nrm;
-            if constexpr (CT) nrm = mesh_normal_kept(op.mesh, G, h.aux);
-            else nrm = mesh_normal_impl<false>(op.mesh, X.x, X.y, h.aux);
-            c[0 * 256] = X.x; c[1 * 256] = X.y; c[2 * 256] = X.z;
-            c[6 * 256] = nrm.x; c[7 * 256] = nrm.y; c[8 * 256] = nrm.z;
-        } else args.cand_aux[crun + (size_t)i] = XRT_CAND_DEAD;
+        if constexpr (DEFER) {
+            if (h.hit != 0) {
+                c[0 * 256] = X.x; c[1 * 256] = X.y; c[2 * 256] = X.z;
+                c[6 * 256] = __hiloint2double(0, idx);
+                args.cand_aux[crun + (size_t)i] = (uint32_t)h.aux;          // (the face that was hit: where the interpolation's walk starts)
+            } else args.cand_aux[crun + (size_t)i] = XRT_CAND_DEAD;
+        } else {
+            alive = (h.hit != 0) && check_bounds<true>(op, X);
+            if (alive) {
+                const V3 nrm = mesh_normal_impl<false>(op.mesh, X.x, X.y, h.aux);
+                c[0 * 256] = X.x; c[1 * 256] = X.y; c[2 * 256] = X.z;
+                c[6 * 256] = nrm.x; c[7 * 256] = nrm.y; c[8 * 256] = nrm.z;
+            } else args.cand_aux[crun + (size_t)i] = XRT_CAND_DEAD;
+        }
     }
+    if constexpr (DEFER) return;
     const unsigned long long ab = __ballot(alive);
     if ((threadIdx.x & 63u) == 0u) {
         const uint32_t n = (uint32_t)__popcll(ab);
@@ -2886,7 +2893,7 @@ static size_t mesh_bytes(const xrt_mesh_t* m)
     b += al256((n_first + 1) * 96);                                   // point-source form of the first pass
     if (Cn > 0) b += al256(F * 128);                                  // plane form of every face (second pass)
     b += al256(P * 16) + al256(F * 8);                                // 16-bit tables of the LDS form
-    b += al256(32 * 32 * 8);                                          // direction grid of the point-source form
+    b += al256(128 * 128 * 16);                                       // direction grid of the point-source form
     return b;
 }
 static size_t meshes_bytes(const xrt_scene_t* sc)
@@ -3543,7 +3550,8 @@ static int upload_meshes(const xrt_scene_t* sc, char* ws, int n_runs, KScene* ks
                     k.pt_rec = (const double*)put(pt.data(), pt.size() * 8);
                     // ---- direction grid (see KMesh.dg_n) ----
                     k.dg_n = 0;
-                    if (n_first >= 8 && n_first < 0xfe && !env_on("XICSRT_NO_DIR_GRID")) {
+                    k.dg_big = n_first >= 0xfe ? 1 : 0;
+                    if (n_first >= 8 && n_first < 0xfffe && !env_on("XICSRT_NO_DIR_GRID")) {
                         double ez[3] = {0, 0, 0};
                         bool ok = true;
                         for (size_t i = 0; i < n_first; i++)
@@ -3590,10 +3598,12 @@ static int upload_meshes(const xrt_scene_t* sc, char* ws, int n_runs, KScene* ks
                         if (ok) {
                             int G = 4 * (int)ceil(sqrt((double)n_first));
                             if (G < 8) G = 8;
-                            if (G > 32) G = 32;
+                            if (G > (k.dg_big ? 128 : 32)) G = k.dg_big ? 128 : 32;
+                            const int CW = k.dg_big ? 4 : 2, IDB = k.dg_big ? 16 : 8;          // words per cell, bits per face number
+                            const uint32_t IDM = k.dg_big ? 0xffffu : 0xffu;
                             const double mx = 1e-6 * extx, my = 1e-6 * exty;       // (a miss by this much in the image is a miss by >= 1e-6 in barycentric units)
                             const double x0 = lo2[0] - 2 * mx, y0 = lo2[1] - 2 * my, hx = (extx + 4 * mx) / G, hy = (exty + 4 * my) / G;
-                            std::vector<uint32_t> cellsd((size_t)G * G * 2, 0xffffffffu);
+                            std::vector<uint32_t> cellsd((size_t)G * G * CW, 0xffffffffu);
                             std::vector<int> cnt((size_t)G * G, 0);
                             for (size_t i = 0; i < n_first; i++) {              // ascending face index within a cell
                                 const double* g = &img[6 * i];
@@ -3625,14 +3635,15 @@ static int upload_meshes(const xrt_scene_t* sc, char* ws, int n_runs, KScene* ks
                                         if (apart) continue;
                                         const size_t c = (size_t)cy * G + cx;
                                         if (cnt[c] < 8) {
-                                            uint32_t& wd = cellsd[2 * c + (cnt[c] >> 2)];
-                                            const int sh = 8 * (cnt[c] & 3);
-                                            wd = (wd & ~(0xffu << sh)) | ((uint32_t)i << sh);
+                                            const int per = 32 / IDB;
+                                            uint32_t& wd = cellsd[CW * c + (cnt[c] / per)];
+                                            const int sh = IDB * (cnt[c] % per);
+                                            wd = (wd & ~(IDM << sh)) | ((uint32_t)i << sh);
                                         }
                                         cnt[c]++;
                                     }
                             }
-                            for (size_t c = 0; c < cnt.size(); c++) if (cnt[c] > 8) cellsd[2 * c] = 0xfffffffeu;
+                            for (size_t c = 0; c < cnt.size(); c++) if (cnt[c] > 8) cellsd[CW * c] = 0xfffffffeu;
                             k.dg_n = G; k.dg_x0 = x0; k.dg_y0 = y0; k.dg_ihx = 1.0 / hx; k.dg_ihy = 1.0 / hy;
                             for (int c = 0; c < 3; c++) { k.dg_ex[c] = ex[c]; k.dg_ey[c] = ey[c]; k.dg_ez[c] = ez[c]; }
                             k.dg_cells = (const uint32_t*)put(cellsd.data(), cellsd.size() * 4);
@@ -3776,6 +3787,7 @@ static int upload_meshes(const xrt_scene_t* sc, char* ws, int n_runs, KScene* ks
                     if (!all) continue;
                     const auto it = simplex_of.find(sorted3(pi[0], pi[1], pi[2]));
                     if (it != simplex_of.end()) fs[i] = it->second;
+                    else fs[i] = m->ct_vertex_simplex[pi[0]];          // (another triangulation: a simplex at one of the face's vertices)
                 }
                 k.face_simplex = (gip)put(fs.data(), F * 4);
             }
@@ -3892,7 +3904,7 @@ static int upload_meshes(const xrt_scene_t* sc, char* ws, int n_runs, KScene* ks
         ks->opt[e].mesh_lds_bytes = k.lds_bytes;
         ks->opt[e].mesh_ct_lds_bytes = (m->interpolate && (size_t)m->n_points * 96 + 64 <= 160u * 1024u && !env_on("XICSRT_NO_MESH_LDS"))
                                            ? (int32_t)((size_t)m->n_points * 96) : 0;
-        ks->opt[e].mesh_dir_bytes = k.dg_n > 0 ? (int32_t)(((size_t)k.n_first + 1) * 96 + (size_t)k.dg_n * k.dg_n * 8) : 0;
+        ks->opt[e].mesh_dir_bytes = (k.dg_n > 0 && !k.dg_big) ? (int32_t)(((size_t)k.n_first + 1) * 96 + (size_t)k.dg_n * k.dg_n * 8) : 0;
         base += mesh_bytes(m);
     }
     return 0;
@@ -4400,33 +4412,36 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
             }
             KArgs am = a;
             const bool ct = sc->optics[be].mesh && sc->optics[be].mesh->interpolate;
-            const int lds_m = ks.opt[be].mesh_lds_bytes;
+            const int lds_m = ks.opt[be].mesh_lds_bytes, lds_ct = ct ? ks.opt[be].mesh_ct_lds_bytes : 0;
+            static thread_local int c_dev3 = -1, c_cus3 = 256;
+            if (c_dev3 != dev_now) { HIP_TRY(hipDeviceGetAttribute(&c_cus3, hipDeviceAttributeMultiprocessorCount, dev_now)); c_dev3 = dev_now; }
+            // (the kernels with tables in LDS: one workgroup of 1024 per CU, blocks of 1024 rays round robin)
+            const uint32_t bpu4 = (bpu + 3u) / 4u;
+            const unsigned long long items = (unsigned long long)n_runs * (unsigned long long)(S * M) * bpu4;
+            const unsigned grid = (unsigned)(items < (unsigned long long)c_cus3 ? items : (unsigned long long)c_cus3);
+            const uint32_t n_units = (uint32_t)(n_runs * S * M);
+            // up to the hit face (an interpolated mesh: the rest is the next launch's)
             if (lds_m > 0) {
-                // the mesh's tables in LDS: one workgroup of 1024 per CU, blocks of 1024 rays round robin
-                static thread_local int c_dev3 = -1, c_cus3 = 256;
-                if (c_dev3 != dev_now) { HIP_TRY(hipDeviceGetAttribute(&c_cus3, hipDeviceAttributeMultiprocessorCount, dev_now)); c_dev3 = dev_now; }
-                const uint32_t bpu4 = (bpu + 3u) / 4u;
-                const unsigned long long items = (unsigned long long)n_runs * (unsigned long long)(S * M) * bpu4;
-                const unsigned grid = (unsigned)(items < (unsigned long long)c_cus3 ? items : (unsigned long long)c_cus3);
                 if (ct) {
                     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(xrt_mesh_rest_lds_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_m));
-                    hipLaunchKernelGGL((xrt_mesh_rest_lds_kernel<true>), dim3(grid), dim3(XRT_MESH_LDS_THREADS), (size_t)lds_m, stream, device_scene(ws), am, be, bpu4, (uint32_t)(n_runs * S * M));
-                    HIP_TRY(hipGetLastError());
-                    const int lds_ct = ks.opt[be].mesh_ct_lds_bytes;
-                    if (lds_ct > 0) {
-                        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(xrt_mesh_ct_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_ct));
-                        hipLaunchKernelGGL(xrt_mesh_ct_lds_kernel, dim3(grid), dim3(XRT_MESH_LDS_THREADS), (size_t)lds_ct, stream, device_scene(ws), am, be, bpu4, (uint32_t)(n_runs * S * M));
-                    } else
-                    hipLaunchKernelGGL(xrt_mesh_ct_kernel, dim3((unsigned)blocks), dim3(XRT_TILE), 0, stream, device_scene(ws), am, be, bpu);
+                    hipLaunchKernelGGL((xrt_mesh_rest_lds_kernel<true>), dim3(grid), dim3(XRT_MESH_LDS_THREADS), (size_t)lds_m, stream, device_scene(ws), am, be, bpu4, n_units);
                 } else {
                     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(xrt_mesh_rest_lds_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_m));
-                    hipLaunchKernelGGL((xrt_mesh_rest_lds_kernel<false>), dim3(grid), dim3(XRT_MESH_LDS_THREADS), (size_t)lds_m, stream, device_scene(ws), am, be, bpu4, (uint32_t)(n_runs * S * M));
+                    hipLaunchKernelGGL((xrt_mesh_rest_lds_kernel<false>), dim3(grid), dim3(XRT_MESH_LDS_THREADS), (size_t)lds_m, stream, device_scene(ws), am, be, bpu4, n_units);
                 }
-            } else
-            if (ct)
+            } else if (ct)
                 hipLaunchKernelGGL((xrt_mesh_rest_kernel<true>), dim3((unsigned)blocks), dim3(XRT_TILE), 0, stream, device_scene(ws), am, be, bpu);
             else
                 hipLaunchKernelGGL((xrt_mesh_rest_kernel<false>), dim3((unsigned)blocks), dim3(XRT_TILE), 0, stream, device_scene(ws), am, be, bpu);
+            HIP_TRY(hipGetLastError());
+            // interpolation, bounds, counts
+            if (ct) {
+                if (lds_ct > 0) {
+                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(xrt_mesh_ct_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_ct));
+                    hipLaunchKernelGGL(xrt_mesh_ct_lds_kernel, dim3(grid), dim3(XRT_MESH_LDS_THREADS), (size_t)lds_ct, stream, device_scene(ws), am, be, bpu4, n_units);
+                } else
+                    hipLaunchKernelGGL(xrt_mesh_ct_kernel, dim3((unsigned)blocks), dim3(XRT_TILE), 0, stream, device_scene(ws), am, be, bpu);
+            }
             HIP_TRY(hipGetLastError());
             if (ti >= 0) HIP_TRY(hipEventRecord(timing_ev[ti][1], stream));
             HIP_TRY(hipMemsetAsync(ws, 0, 64, stream));
