@@ -141,7 +141,7 @@ RTOL_CASE = {'I2_ToroidalCrystal_trace': 1e-9}
 # and is recorded 24 km away, a ray on a double root of the torus quartic.  The oracle (libm) agrees with the reference to
 # 7e-13 there; the device (its own square roots, divisions and last-ulp transcendental differences, amplified by the
 # ill-conditioned point) to 1.7e-9 and 1.3e-8.  Masks, counters and pixels are equal; the task's bound is 1e-6.
-RTOL_CASE_DEVICE = {'Y_fuzz_9011073_trace': 1e-7, 'Y_fuzz_9015074_trace': 1e-7}
+RTOL_CASE_DEVICE = {'Y_fuzz_9011073_trace': 1e-7, 'Y_fuzz_9015074_trace': 1e-7, 'Y_fuzz_14039276_trace': 1e-7}
 
 
 def rtol_for(name, device=False):
