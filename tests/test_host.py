@@ -183,6 +183,25 @@ def test_supported_scenes_validate():
         assert L.xrt_workspace_bytes(flat.byref(), 10) > 10 * 4096
 
 
+def test_workspace_of_a_mesh_crystal_holds_the_parked_rays_within_the_budget(monkeypatch):
+    """A mesh crystal goes through three launches with the rays that hit a face parked in HBM (room for 10 doubles + the face per ray
+    of capacity, per 64 rays and per unit the number left alive): the workspace the library asks for holds them -- cfg5 at its
+    full size 84 GB -- up to twice the one-pass budget (96 GiB); beyond it, and with the route switched off, the scene takes
+    the one-kernel route and asks for no candidate arrays."""
+    L = capi.lib()
+    cfg, _ = helpers.load_golden('E_cfg5_mesh_flat_1e5')
+    cfg['sources']['source']['intensity'] = 1000000
+    config, elements, flat = helpers.build(cfg)
+    L.xrt_workspace_bytes.restype = C.c_size_t
+    full = L.xrt_workspace_bytes(flat.byref(), 1000)
+    parked = 1000 * 1000192 * (10 * 8 + 4)
+    assert parked < full < parked + (4 << 30)
+    too_many = L.xrt_workspace_bytes(flat.byref(), 2000)
+    assert too_many < (16 << 30)                      # 168 GB of parked rays: not asked for
+    monkeypatch.setenv('XICSRT_NO_MESH_SPLIT', '1')
+    assert L.xrt_workspace_bytes(flat.byref(), 1000) < (8 << 30)
+
+
 def test_mesh_tables_match_reference():
     """Mesh generators and the pre-computed face / Clough-Tocher tables are bit-identical to the reference's
     (optics/_ShapeMesh*.py; fixtures T_tables_* written by tests/golden/make_golden.py)."""
