@@ -2529,7 +2529,9 @@ void xrt_mesh_rest_lds_kernel(const KScene* __restrict__ scene_g, const KArgs ar
         if (have) {
             const int face = (int)args.cand_aux[crun + (size_t)i];
             int idx;
-            const MeshHit h = mesh_rest_lds(Mp, L, c[0 * 256], c[1 * 256], c[2 * 256], c[3 * 256], c[4 * 256], c[5 * 256], face, idx);
+            V3 nrm;
+            nrm.x = nrm.y = nrm.z = 0.0;
+            const MeshHit h = mesh_rest_lds(Mp, L, c[0 * 256], c[1 * 256], c[2 * 256], c[3 * 256], c[4 * 256], c[5 * 256], face, idx, nrm);
             V3 X;
             X.x = h.x; X.y = h.y; X.z = h.z;
             if constexpr (DEFER) {
@@ -2541,7 +2543,6 @@ void xrt_mesh_rest_lds_kernel(const KScene* __restrict__ scene_g, const KArgs ar
             } else {
                 alive = (h.hit != 0) && check_bounds<true>(op, X);
                 if (alive) {
-                    const V3 nrm = mesh_normal_impl<false>(Mp, X.x, X.y, h.aux);
                     c[0 * 256] = X.x; c[1 * 256] = X.y; c[2 * 256] = X.z;
                     c[6 * 256] = nrm.x; c[7 * 256] = nrm.y; c[8 * 256] = nrm.z;
                 } else args.cand_aux[crun + (size_t)i] = XRT_CAND_DEAD;
