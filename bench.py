@@ -117,9 +117,19 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     # XICSRT_BENCH_FORCE_DIST=1 exercises the RCCL path with a single rank (launched through torchrun)
     use_dist = world > 1 or (os.environ.get('XICSRT_BENCH_FORCE_DIST') == '1' and 'RANK' in os.environ)
+    # a line for N GPUs must come from N ranks: refuse, before any GPU work, rather than print a number that is not what it says
+    if not use_dist and args.gpus != 1:
+        sys.stderr.write('bench.py: --gpus %d needs one process per GPU (torch.distributed.run); no line printed\n' % args.gpus)
+        sys.exit(2)
     if use_dist:
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+        if dist.get_world_size() != args.gpus:
+            if rank == 0:
+                sys.stderr.write('bench.py: --gpus %d but the process group has %d ranks; no line printed\n'
+                                 % (args.gpus, dist.get_world_size()))
+            dist.destroy_process_group()
+            sys.exit(2)
     else:
         torch.cuda.set_device(0)
     lib = capi.lib()
@@ -163,17 +173,6 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-
-    if use_dist and dist.get_world_size() != args.gpus:
-        # a line for N GPUs must come from N ranks: refuse rather than print a number that is not what it says
-        if rank == 0:
-            sys.stderr.write('bench.py: --gpus %d but the process group has %d ranks; no line printed\n'
-                             % (args.gpus, dist.get_world_size()))
-        dist.destroy_process_group()
-        sys.exit(2)
-    if not use_dist and args.gpus != 1:
-        sys.stderr.write('bench.py: --gpus %d needs one process per GPU (torch.distributed.run); no line printed\n' % args.gpus)
-        sys.exit(2)
 
     # What users call: xicsrt_amd.raytrace(config) of the same scene (keep_history=False), whole call on the host clock,
     # and the part of it that is object construction (SURVEY 8d prices the call without it).  Outside the timed region.

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define XRT_ABI_VERSION 17
+#define XRT_ABI_VERSION 18
 
 #define XRT_MAX_OPTICS     64
 #define XRT_MAX_APERTURES  32
@@ -368,6 +368,14 @@ int xrt_make_image(const xrt_optic_t* optic, int64_t n, const double* rays, cons
  * tools/xicsrt_voigt.py); -10 a plasma source generated no ray at all in some iteration ("No rays generated",
  * _XicsrtPlasmaGeneric.py:368-369).  0 = clean. */
 int xrt_check(void* workspace, void* stream);
+
+/* The device status word xrt_check reads: a uint32 at this byte offset of the workspace (0 = nothing to report; the
+ * bits are private to xrt_check, which words them).  Cleared at the start of every xrt_trace / xrt_trace_history call.
+ * Exported so that a binding which already copies its results back can fetch the word in the same batch of
+ * asynchronous copies and call xrt_check only when it is non-zero.  xrt_status_offset() returns the offset the
+ * library was built with; a binding verifies it equals XRT_WS_STATUS_BYTE at load time.  No reference counterpart. */
+#define XRT_WS_STATUS_BYTE 64
+size_t xrt_status_offset(void);
 
 /* TraceObject.intersect / check_bounds / interact as separate calls on a caller's ray array
  * (optics/_TraceObject.py:157-180 `trace`: xloc, norm, mask = intersect(rays); mask = check_bounds(xloc, mask);

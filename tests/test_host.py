@@ -147,6 +147,22 @@ def test_library_exports_every_declared_symbol():
     assert L.xrt_sizeof_scene() == C.sizeof(xscene.Scene)
 
 
+def test_device_sources_compile_without_warnings():
+    """The HIP sources pass `-Wall -Werror` (host and gfx950 passes, front end only: seconds): a new warning fails here, and
+    build.sh, which carries -Werror, would refuse to build."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('no hipcc here')
+    csrc = os.path.join(helpers.ROOT, 'xicsrt_amd', 'csrc')
+    assert '-Wall' in open(os.path.join(csrc, 'build.sh')).read() and '-Werror' in open(os.path.join(csrc, 'build.sh')).read()
+    res = subprocess.run([hipcc, '--offload-arch=gfx950', '-std=c++17', '-fsyntax-only', '-Wall', '-Wno-unused-function',
+                          '-Werror', '-Wno-unused-command-line-argument', 'xrt_kernels.hip'],
+                         cwd=csrc, capture_output=True, text=True)
+    assert res.returncode == 0 and 'warning' not in res.stderr, res.stderr[-3000:]
+
+
 def test_unsupported_scenes_fail_loudly():
     """No CPU fallback: features outside the device path are refused (class lookup or xrt_scene_check)."""
     L = capi.lib()

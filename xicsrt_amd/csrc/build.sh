@@ -14,7 +14,7 @@ $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared \
     -ffp-contract=off -fno-fast-math \
     -mllvm -instcombine-max-copied-from-constant-users=10000 \
     -mllvm -disable-machine-licm \
-    -Wall -Wno-unused-function \
+    -Wall -Wno-unused-function -Werror -Wno-error=unused-command-line-argument \
     ${XRT_EXTRA_FLAGS} \
     -o ${XRT_OUT:-libxicsrt_hip.so} xrt_kernels.hip
 echo "built $(pwd)/${XRT_OUT:-libxicsrt_hip.so}"

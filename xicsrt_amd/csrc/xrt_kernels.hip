@@ -1537,7 +1537,11 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
             lds_barrier();
         };
         auto stamp = [&](int k) __attribute__((always_inline)) {
+#ifdef XRT_UNIT_CLOCKS
             if (SEG && args.dbg && tid == 0) args.dbg[(size_t)unit * 8 + k] = wall_clock64();
+#else
+            (void)k;
+#endif
         };
         stamp(0);
         if constexpr (SEG == 2) __builtin_amdgcn_s_setprio(2);       // (first phase: above the units in their second phase)
@@ -1586,7 +1590,7 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
                                 ray.o = to_local(op.R, sub3(ray.o, ld3(op.origin)));
                                 ray.d = to_local(op.R, ray.d);
                             }
-                            bool hit;
+                            bool hit = false;
                             if (is_mesh && e == be && mesh_pre && !counting) {
                                 // queued with its (local-frame) origin and the face of the first pass; see mesh_pre
                                 bool by_grid = false;
@@ -2040,7 +2044,9 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
                 lds_barrier();
                 const unsigned long long before = uni64(*acc);
                 stamp(3);
+#ifdef XRT_UNIT_CLOCKS
                 if (args.dbg && tid == 0) args.dbg[(size_t)unit * 8 + 7] = ((unsigned long long)n_candidates << 32) | (before & 0xffffffffull);
+#endif
                 // ---- second phase, wave by wave and without workgroup barriers (a barrier in front of every dependent step of
                 // a 256-candidate batch -- uniforms, test, survivor scan, drain -- left the vector units idle two thirds of the
                 // time).  Each of the four waves takes a quarter of the unit's candidates (a little less for the later ones, which
@@ -2356,7 +2362,9 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
         }
 
         stamp(5);
+#ifdef XRT_UNIT_CLOCKS
         if (SEG && args.dbg && tid == 0) args.dbg[(size_t)unit * 8 + 6] = cnt[be >= 0 ? be + 1 : 0];
+#endif
 
         // ---- run done: counters out, stream head back to memory ---------------
         // canonical form: exactly 512 words generated ahead (what xrt_jump_kernel expects)
@@ -4082,7 +4090,7 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
         ps.dump_words = (uint32_t)plasma_dump_words(sc);
         // (slot strides: the arrays are indexed [slot][...] with the unpadded sizes; al256 only pads the regions)
         ps.gauss_state = reinterpret_cast<KState*>(ws + ws_off_gauss(sc, n_runs));
-        ps.flags = reinterpret_cast<uint32_t*>(ws) + 16;
+        ps.flags = reinterpret_cast<uint32_t*>(ws + XRT_WS_STATUS_BYTE);
         a.n_src_heads = 0;
         a.run_counter = reinterpret_cast<uint32_t*>(ws);
         a.progress = env_on("XICSRT_NO_PRIORITY_FEEDBACK") ? nullptr : reinterpret_cast<unsigned long long*>(ws + 32);
@@ -4125,7 +4133,7 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
         g.aux = g.ids + (size_t)slots * (size_t)N;
         g.act = g.aux + (size_t)slots * (size_t)N;
         g.bundle_off = reinterpret_cast<double*>(base + (size_t)slots * (size_t)N * (XRT_ST_ARRAYS * sizeof(double) + 3 * sizeof(uint32_t)));
-        g.flags = reinterpret_cast<uint32_t*>(ws) + 16;        // status word in the 256-byte workspace header
+        g.flags = reinterpret_cast<uint32_t*>(ws + XRT_WS_STATUS_BYTE);        // status word in the 256-byte workspace header
         if (sc->source.plasma && sc->source.plasma->voigt_gamma > 0.0)      // behind the bundle tables and the per-slot counts
             g.voigt_tab = g.bundle_off + (size_t)slots * XRT_ST_BUNDLE_ROWS * (size_t)(sc->source.bundle_count > 0 ? sc->source.bundle_count : 0) + 2 * (size_t)slots;
         g.gauss_state = reinterpret_cast<KState*>(ws + ws_off_gauss(sc, n_runs));
@@ -4363,7 +4371,9 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
             g_paths |= XRT_PATH_ONE_PASS;
         }
         a.dbg = nullptr;
-        if (const char* e = getenv("XICSRT_UNIT_CLOCKS")) a.dbg = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0));   // development: device buffer [units][8]
+#ifdef XRT_UNIT_CLOCKS      // development builds only (XRT_EXTRA_FLAGS=-DXRT_UNIT_CLOCKS=1): a device buffer [units][8] of phase stamps
+        if (const char* e = getenv("XICSRT_UNIT_CLOCKS")) a.dbg = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0));
+#endif
 
         a.wl_array = nullptr; a.base_words = nullptr;
         if (n_gch > 0) {
@@ -4374,7 +4384,7 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
             gk.heads = dst + (size_t)S * nh + n_ch; gk.run_stride = nj; gk.pairs_per_chunk = plan.gpairs; gk.n_values = N;
             gk.n_chunks = n_gch; gk.n_runs = n_runs; gk.acc = d_gacc; gk.wl = d_wl; gk.end_words = d_gend;
             gk.loc = sc->source.wavelength; gk.sigma = sc->source.wl_a;
-            gk.counter = reinterpret_cast<uint32_t*>(ws); gk.flags = reinterpret_cast<uint32_t*>(ws) + 16;
+            gk.counter = reinterpret_cast<uint32_t*>(ws); gk.flags = reinterpret_cast<uint32_t*>(ws + XRT_WS_STATUS_BYTE);
             int gunits = n_runs * n_gch, ggrid = gunits < 1024 ? gunits : 1024;
             for (int mode = (n_gch > 1 ? 1 : 2); mode <= 2; mode++) {
                 gk.mode = mode;
@@ -4549,7 +4559,7 @@ static int trace_runs(const xrt_scene_t* sc, const uint32_t* seeds, int32_t n_ru
     HIP_TRY(hipGetLastError());
     st = upload_tables(sc, ws, stream);
     if (st) return st;
-    if (clear_status) HIP_TRY(hipMemsetAsync(ws + 64, 0, 64, stream));           // status word
+    if (clear_status) HIP_TRY(hipMemsetAsync(ws + XRT_WS_STATUS_BYTE, 0, 64, stream));           // status word
     KScene ks;
     build_kscene(sc, ws, &ks);
     st = upload_meshes(sc, ws, n_runs, &ks, stream);
@@ -4615,7 +4625,7 @@ extern "C" int xrt_trace_history(const xrt_scene_t* sc, const xrt_rng_state_t* s
     HIP_TRY(hipGetLastError());
     st = upload_tables(sc, ws, stream);
     if (st) return st;
-    HIP_TRY(hipMemsetAsync(ws + 64, 0, 64, stream));           // status word
+    HIP_TRY(hipMemsetAsync(ws + XRT_WS_STATUS_BYTE, 0, 64, stream));           // status word
     KScene ks;
     build_kscene(sc, ws, &ks);
     st = upload_meshes(sc, ws, 1, &ks, stream);
@@ -4969,13 +4979,15 @@ extern "C" uint32_t xrt_last_path(int32_t reset)
     return p;
 }
 
+extern "C" size_t xrt_status_offset(void) { return XRT_WS_STATUS_BYTE; }
+
 extern "C" int xrt_check(void* workspace, void* stream_)
 {
     if (!workspace) return fail(-1, "%s", "NULL argument");
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     uint32_t flags = 0;
     HIP_TRY(hipStreamSynchronize(stream));
-    HIP_TRY(hipMemcpy(&flags, reinterpret_cast<char*>(workspace) + 64, sizeof(flags), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&flags, reinterpret_cast<char*>(workspace) + XRT_WS_STATUS_BYTE, sizeof(flags), hipMemcpyDeviceToHost));
     if (flags & 2u)
         return fail(-7, "%s", "intensity of less than one encountered. Turn on poisson statistics.");
     if (flags & 4u)

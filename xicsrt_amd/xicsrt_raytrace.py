@@ -44,7 +44,6 @@ from . import xicsrt_io
 
 m_log = logging.getLogger('xicsrt')
 
-_RAY_KEYS = ('origin', 'direction', 'mask', 'wavelength')
 
 
 # ---------------------------------------------------------------------------
@@ -343,7 +342,7 @@ class DeviceTrace:
         if self._acc_host is None:
             self._acc_host = t.empty(self._acc.numel(), dtype=t.int64, pin_memory=True)
             self._flags_host = t.empty(4, dtype=t.uint8, pin_memory=True)
-        self._flags_host.copy_(self._ws[64:68], non_blocking=True)
+        self._flags_host.copy_(self._ws[xscene.XRT_WS_STATUS_BYTE:xscene.XRT_WS_STATUS_BYTE + 4], non_blocking=True)
         self._acc_host.copy_(self._acc, non_blocking=True)
         t.cuda.current_stream().synchronize()
         if int(self._flags_host.view(t.int32)[0]) != 0:
@@ -490,69 +489,68 @@ def _sorted_history_from_device(elements, device, d_rays, d_mask, rng, max_lost)
     return found, lost
 
 
-def combine_raytrace(input_list, keep_images=True, components=None):
-    """Combine result dictionaries: sum meta and images, concatenate histories."""
-    output = _empty_output(input_list[0]['config'])
-    num = len(input_list)
-    if components is None:
-        key_opt_list = list(input_list[0]['total']['meta'].keys())
-    else:
-        key_opt_list = components
-    key_opt_last = key_opt_list[-1]
+def _summed_meta(results, names):
+    """total/meta of the merged result: per element, every counter of the first result summed over all results."""
+    merged = {}
+    for name in names:
+        counters = results[0]['total']['meta'][name]
+        merged[name] = {counter: sum(res['total']['meta'][name][counter] for res in results) for counter in counters}
+    return merged
 
-    for key_opt in key_opt_list:
-        output['total']['meta'][key_opt] = {}
-        for key_meta in input_list[0]['total']['meta'][key_opt]:
-            total = 0
-            for entry in input_list:
-                total += entry['total']['meta'][key_opt][key_meta]
-            output['total']['meta'][key_opt][key_meta] = total
 
-    if keep_images:
-        for key_opt in key_opt_list:
-            if key_opt not in input_list[0]['total']['image']:
-                continue
-            first = input_list[0]['total']['image'][key_opt]
-            if first is None:
-                output['total']['image'][key_opt] = None
-                continue
-            if all(entry['total']['image'][key_opt].shape == first.shape for entry in input_list):
-                acc = np.zeros(first.shape)
-                for entry in input_list:
-                    acc += entry['total']['image'][key_opt]
-                output['total']['image'][key_opt] = acc
+def _summed_images(results, names):
+    """total/image of the merged result.  An element the first result has no image entry for gets none; an element
+    without pixel grid stays None; pixel grids of different shapes cannot be added: warning and None."""
+    merged = {}
+    for name in names:
+        if name not in results[0]['total']['image']:
+            continue
+        stack = [res['total']['image'][name] for res in results]
+        if stack[0] is None:
+            merged[name] = None
+        elif len({np.shape(img) for img in stack}) == 1:
+            merged[name] = np.add.reduce(np.asarray(stack, dtype=np.float64), axis=0)
+        else:
+            m_log.warning('Image dimensions do not match. Cannot combine images.')
+            merged[name] = None
+    return merged
+
+
+def _joined_history(results, group, names):
+    """found/history or lost/history of the merged result: per element the four ray fields of a RayArray (a source's
+    `weight` is not one of them, App. C.7) of all results one after the other, in the order of `results`.  How many
+    rays a result contributes is read off its last element (every element of one result holds the same rays)."""
+    counts = [len(res[group]['history'][names[-1]]['mask']) for res in results]
+    blank = RayArray()
+    blank.zeros(0)
+    merged = {}
+    for name in names:
+        rays = RayArray()
+        for field, empty in blank.items():
+            parts = [np.asarray(res[group]['history'][name][field])[:cnt] for res, cnt in zip(results, counts)]
+            if len(parts) == 1 and parts[0].dtype == empty.dtype:
+                rays[field] = np.ascontiguousarray(parts[0])        # one result: its arrays are the answer
             else:
-                m_log.warning('Image dimensions do not match. Cannot combine images.')
-                output['total']['image'][key_opt] = None
+                rays[field] = np.concatenate([empty] + parts).astype(empty.dtype, copy=False)
+        merged[name] = rays
+    return merged
 
-    if len(input_list[0]['found']['history']) > 0:
+
+def combine_raytrace(input_list, keep_images=True, components=None):
+    """
+    One result dictionary (SURVEY 8b "Result schema") out of several: `config` of the first, `total/meta` summed,
+    `total/image` summed (keep_images), `found` / `lost` histories joined when the results carry any.  `components`
+    restricts the merge to the named elements.  (Contract: xicsrt/xicsrt_raytrace.py:281-393.)
+    """
+    results = list(input_list)
+    names = list(results[0]['total']['meta']) if components is None else list(components)
+    output = _empty_output(results[0]['config'])
+    output['total']['meta'] = _summed_meta(results, names)
+    if keep_images:
+        output['total']['image'] = _summed_images(results, names)
+    if len(results[0]['found']['history']) > 0:
         for group in ('found', 'lost'):
-            if num == 1:
-                # one entry: its arrays are the result (the other ray fields zero, as below)
-                for key_opt in key_opt_list:
-                    h = input_list[0][group]['history'][key_opt]
-                    rays = RayArray()
-                    rays.zeros(0)
-                    for name in list(rays):
-                        if name not in _RAY_KEYS:
-                            rays[name] = np.zeros((len(h['mask']),) + rays[name].shape[1:], dtype=rays[name].dtype)
-                    for key_ray in _RAY_KEYS:
-                        rays[key_ray] = np.ascontiguousarray(h[key_ray])
-                    output[group]['history'][key_opt] = rays
-                continue
-            total = sum(len(entry[group]['history'][key_opt_last]['mask']) for entry in input_list)
-            for key_opt in key_opt_list:
-                rays = RayArray()
-                rays.zeros(total)
-                index = 0
-                for entry in input_list:
-                    h = entry[group]['history'][key_opt]
-                    cnt = len(entry[group]['history'][key_opt_last]['mask'])
-                    for key_ray in _RAY_KEYS:
-                        rays[key_ray][index:index + cnt] = h[key_ray][:]
-                    index += cnt
-                output[group]['history'][key_opt] = rays
-    assert num == len(input_list)
+            output[group]['history'] = _joined_history(results, group, names)
     return output
 
 
@@ -709,7 +707,9 @@ def raytrace(config):
     num_runs = general['number_of_runs']
     seeds = run_seeds(general['random_seed'], num_runs)
     dist, rank, world = _dist()
-    distributed = dist is not None and world > 1
+    # (a group of ONE rank takes the same branch: the collectives are then RCCL calls that move nothing, and the code that
+    #  runs on eight GPUs is the code that runs on one)
+    distributed = dist is not None
     if distributed and general['random_seed'] is None:
         # every rank must use the same (random) seeds: rank 0's
         box = [seeds]
@@ -780,12 +780,84 @@ def raytrace(config):
     return _finish(output, general)
 
 
+def visible_devices():
+    """HIP devices this process can launch on (torch.cuda.device_count() does not initialise the GPU)."""
+    import torch
+    return int(torch.cuda.device_count())
+
+
+def device_scope(index):
+    """Context that makes device `index` the calling thread's current device."""
+    import torch
+    return torch.cuda.device(index)
+
+
+def _trace_on_device(config_in, index, width, seeds, per_run_images):
+    """What one pool worker of the reference does for its runs (xicsrt_multiprocessing.py:40-53), on one device:
+    runs index, index + width, ... through the C ABI on that device's stream; the host copies of its sums."""
+    with device_scope(index):
+        run_outputs, device, cfg = _raytrace_runs(copy.deepcopy(config_in), shard_runs(len(seeds), index, width), seeds,
+                                                  internal=True, per_run_images=per_run_images)
+        meta, image = device.results()           # (raises what the device reported)
+    return run_outputs, meta, image, cfg
+
+
+def _raytrace_devices(config, width):
+    """
+    `raytrace` fanned out over `width` devices of this process: one host thread per device (the C ABI is handle-free
+    and takes the stream per call; ctypes releases the interpreter lock for the duration of a call), run i on device
+    i mod width with its own seed, the per-device sums of [num_out | image bins] (120 KB for the bench scene) added
+    on the host, histories put together in run order.  Every partition of the runs gives the same sums.
+    """
+    from concurrent.futures import ThreadPoolExecutor
+    config_in = xconfig.get_config(config)
+    general = config_in['general']
+    seeds = run_seeds(general['random_seed'], general['number_of_runs'])
+    per_run_images = bool(general['save_images'])
+    with ThreadPoolExecutor(max_workers=width) as pool:
+        jobs = [pool.submit(_trace_on_device, config_in, d, width, seeds, per_run_images) for d in range(width)]
+        parts = []
+        failure = None
+        for job in jobs:                         # every device finishes before anything is raised
+            try:
+                parts.append(job.result())
+            except Exception as exc:             # noqa: BLE001 - re-raised below, the first device's first
+                failure = failure or exc
+        if failure is not None:
+            raise failure
+    cfg = parts[0][3]
+    meta = {name: {'num_out': sum(part[1][name]['num_out'] for part in parts)} for name in parts[0][1]}
+    image = {}
+    for name, first in parts[0][2].items():
+        image[name] = None if first is None else np.add.reduce([part[2][name] for part in parts], axis=0)
+    output = _empty_output(cfg)
+    singles = sorted((item for part in parts for item in (part[0] or [])), key=lambda item: item[0])
+    if singles:
+        output = combine_raytrace([single for _, single in singles])
+        output['config'] = cfg
+    output['total']['meta'] = meta if general['keep_meta'] else {}
+    output['total']['image'] = image if general['keep_images'] else {}
+    output['config']['general']['output_run_suffix'] = general['output_run_suffix']
+    output['config']['general']['random_seed'] = general['random_seed']
+    return _finish(output, general)
+
+
 def raytrace_mp(config, processes=None):
     """
-    Drop-in for xicsrt.raytrace_mp: identical results to `raytrace`.  `processes`
-    is accepted for compatibility; parallelism over runs happens on the GPU(s).
+    Drop-in for xicsrt.raytrace_mp (xicsrt_multiprocessing.py:12-81): identical results to `raytrace`.  The reference
+    fans the runs out over a pool of `processes` workers (None: all cores); here over the GPUs of this process --
+    `processes=None`: every visible device, `processes=k`: at most k of them -- one host thread per device, no
+    process group needed.  Under an initialised torch.distributed group (one process per GPU) the runs are already
+    sharded over the ranks and this is `raytrace`.
     """
-    output = raytrace(config)
+    dist, rank, world = _dist()
+    width = 1
+    if dist is None:
+        width = visible_devices()
+        if processes is not None:
+            width = min(width, int(processes))
+        width = max(1, min(width, xconfig.get_config(config)['general']['number_of_runs']))
+    output = raytrace(config) if width <= 1 else _raytrace_devices(config, width)
     # reference quirk kept: raytrace_mp stores output_run_suffix into random_seed
     # (xicsrt_multiprocessing.py:69)
     output['config']['general']['random_seed'] = output['config']['general']['output_run_suffix']
