@@ -377,6 +377,13 @@ int xrt_check(void* workspace, void* stream);
 #define XRT_WS_STATUS_BYTE 64
 size_t xrt_status_offset(void);
 
+/* Caps the budgets the big regions of a workspace are sized to (slots of the staged path, parked candidates of the one-pass
+ * routes; beyond a budget a call works through its runs in batches or takes a leaner route).  The defaults suit a 288 GB
+ * part and scale down with the current device's total memory; a caller whose allocation of xrt_workspace_bytes() failed
+ * passes what it can spare and asks again.  0: back to the defaults.  Process-wide; affects xrt_workspace_bytes and the
+ * calls that follow alike.  No reference counterpart (the reference's working set is whatever NumPy allocates). */
+void   xrt_set_workspace_budget(size_t bytes);
+
 /* TraceObject.intersect / check_bounds / interact as separate calls on a caller's ray array
  * (optics/_TraceObject.py:157-180 `trace`: xloc, norm, mask = intersect(rays); mask = check_bounds(xloc, mask);
  * rays = interact(rays, xloc, norm, mask)).  Analytic shapes (Shape{Plane,Sphere,Cylinder,Torus}.intersect,

@@ -203,7 +203,7 @@ def test_segmented_runs_equal_reference(name, segments, route, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('route', ['split', 'split_tables_in_global', 'split_every_face', 'fused'])
+@pytest.mark.parametrize('route', ['split', 'split_tables_in_global', 'split_every_face', 'split_batches', 'fused'])
 @pytest.mark.parametrize('name', ['E_cfg5_mesh_flat_1e5', 'E_cfg5_mesh_interp_1e5', 'E_mesh_interp_counts', 'E_mesh_norefine_counts',
                                   'E_mesh_81_coarse17_counts'])
 def test_mesh_crystal_routes_equal_reference(name, route, monkeypatch):
@@ -219,6 +219,11 @@ def test_mesh_crystal_routes_equal_reference(name, route, monkeypatch):
         monkeypatch.setenv('XICSRT_NO_DIR_GRID', '1')
     cfg, gold = helpers.load_golden(name)
     config, elements, flat = helpers.build(cfg)
+    if route == 'split_batches':                                    # a budget that holds one of the two runs: batches of runs
+        cap = (flat.n_rays + 255) // 256 * 256
+        whole = capi.lib().xrt_workspace_bytes(flat.byref(), 2)
+        monkeypatch.setenv('XICSRT_WORKSPACE_BUDGET_MB', str(int(1.6 * (cap * 84 + cap // 16)) // (1 << 20) + 1))
+        assert capi.lib().xrt_workspace_bytes(flat.byref(), 2) < whole - cap * 60
     g = config['general']
     seeds = xrt.run_seeds(g['random_seed'], g['number_of_runs'])
     capi.lib().xrt_last_path(1)

@@ -200,20 +200,34 @@ def test_supported_scenes_validate():
 
 
 def test_workspace_of_a_mesh_crystal_holds_the_parked_rays_within_the_budget(monkeypatch):
-    """A mesh crystal goes through three launches with the rays that hit a face parked in HBM (room for 10 doubles + the face per ray
-    of capacity, per 64 rays and per unit the number left alive): the workspace the library asks for holds them -- cfg5 at its
-    full size 84 GB -- up to twice the one-pass budget (96 GiB); beyond it, and with the route switched off, the scene takes
-    the one-kernel route and asks for no candidate arrays."""
+    """A mesh crystal goes through three launches with the rays that hit a face parked in HBM (room for 10 doubles + the face per
+    ray of capacity, per 64 rays and per unit the number left alive: 84 B per ray).  A call whose runs would take more than the
+    budget (48 GiB on a 288 GB part; a cap set through xrt_set_workspace_budget or the environment counts too) goes through
+    them in equal batches of at most 512 runs, and the workspace is that of one batch -- cfg5 at its full size: 2 x 500 runs,
+    42 GB.  With the split switched off: the one-kernel route, no parked rays."""
     L = capi.lib()
     cfg, _ = helpers.load_golden('E_cfg5_mesh_flat_1e5')
     cfg['sources']['source']['intensity'] = 1000000
     config, elements, flat = helpers.build(cfg)
     L.xrt_workspace_bytes.restype = C.c_size_t
+    cap = 1000192
+    per_run = cap * 84
     full = L.xrt_workspace_bytes(flat.byref(), 1000)
-    parked = 1000 * 1000192 * (10 * 8 + 4)
-    assert parked < full < parked + (4 << 30)
-    too_many = L.xrt_workspace_bytes(flat.byref(), 2000)
-    assert too_many < (16 << 30)                      # 168 GB of parked rays: not asked for
+    assert 500 * per_run < full < 500 * per_run + (4 << 30)          # two batches of 500 runs
+    assert full < (48 << 30)
+    assert L.xrt_workspace_bytes(flat.byref(), 4000) == L.xrt_workspace_bytes(flat.byref(), 2000) == full
+    few = L.xrt_workspace_bytes(flat.byref(), 300)
+    assert 300 * per_run < few < 300 * per_run + (4 << 30)           # fits as it is
+    # a tighter budget: smaller batches
+    L.xrt_set_workspace_budget(8 << 30)
+    try:
+        assert L.xrt_workspace_bytes(flat.byref(), 1000) < (8 << 30) + (2 << 30)
+    finally:
+        L.xrt_set_workspace_budget(0)
+    assert L.xrt_workspace_bytes(flat.byref(), 1000) == full
+    monkeypatch.setenv('XICSRT_WORKSPACE_BUDGET_MB', '4096')
+    assert L.xrt_workspace_bytes(flat.byref(), 1000) < (6 << 30)
+    monkeypatch.delenv('XICSRT_WORKSPACE_BUDGET_MB')
     monkeypatch.setenv('XICSRT_NO_MESH_SPLIT', '1')
     assert L.xrt_workspace_bytes(flat.byref(), 1000) < (8 << 30)
 

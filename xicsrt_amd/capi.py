@@ -17,7 +17,7 @@ EXPORTS = (
     'xrt_device_count', 'xrt_workspace_bytes', 'xrt_trace', 'xrt_trace_history',
     'xrt_timing_begin', 'xrt_timing_end', 'xrt_mt_jump_poly', 'xrt_check', 'xrt_make_image', 'xrt_last_path',
     'xrt_optic_intersect', 'xrt_optic_check_bounds', 'xrt_optic_interact', 'xrt_selftest_div3', 'xrt_legacy_shuffle_head',
-    'xrt_status_offset',
+    'xrt_status_offset', 'xrt_set_workspace_budget',
 )
 PATH_FUSED, PATH_STAGED, PATH_STAGE_SPLIT, PATH_JUMP, PATH_SEEK, PATH_SEGMENTED, PATH_GAUSS_PREPARED = 1, 2, 4, 8, 16, 32, 64
 PATH_PLASMA_SCOUT = 128
@@ -86,6 +86,8 @@ def lib():
     L.xrt_legacy_shuffle_head.argtypes = [P(_scene.RngState), C.c_int64, C.c_int64, P(C.c_int64)]
     L.xrt_last_path.argtypes = [C.c_int32]
     L.xrt_status_offset.restype = C.c_size_t
+    L.xrt_set_workspace_budget.restype = None
+    L.xrt_set_workspace_budget.argtypes = [C.c_size_t]
     L.xrt_timing_begin.restype = C.c_int
     L.xrt_timing_end.restype = C.c_int
     L.xrt_timing_end.argtypes = [P(C.c_double), P(C.c_int64)]

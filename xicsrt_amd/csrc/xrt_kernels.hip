@@ -2877,7 +2877,39 @@ static bool needs_staged(const xrt_scene_t* sc)
 // Staged path: one workgroup per slot, one per CU (XRT_ST_SLOTS = 256 CUs), fewer when the per-slot
 // ray arrays of a scene would take more than XRT_ST_BUDGET bytes of workspace in total.
 #define XRT_ST_SLOTS 256
-#define XRT_ST_BUDGET (96ull << 30)
+// Workspace budgets.  The big regions of a workspace -- the slots of the staged path, the parked candidates of the one-pass
+// routes -- are sized to budgets, beyond which a call works through its runs in batches or takes a leaner route.  The
+// budgets are constants for a 288 GB part, scaled down on a device with less memory (a share of its TOTAL memory: the
+// figure must not move between xrt_workspace_bytes and xrt_trace), and capped by xrt_set_workspace_budget (a caller whose
+// allocation failed asks again with what is free) or XICSRT_WORKSPACE_BUDGET_MB.
+#define XRT_ST_BUDGET_MAX   (96ull << 30)
+#define XRT_CAND_BUDGET_MAX (48ull << 30)
+static size_t g_budget_cap = 0;             // xrt_set_workspace_budget: 0 = none
+static size_t device_total_bytes()
+{
+    static thread_local int c_dev = -2;
+    static thread_local size_t c_total = 0;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }       // (no device: the constants)
+    if (dev != c_dev) {
+        size_t total = 0;
+        if (hipDeviceTotalMem(&total, dev) != hipSuccess) { (void)hipGetLastError(); total = 0; }
+        c_dev = dev; c_total = total;
+    }
+    return c_total;
+}
+static size_t budget_of(size_t most, double share)
+{
+    size_t b = most;
+    const size_t total = device_total_bytes();
+    if (total > 0 && (size_t)((double)total * share) < b) b = (size_t)((double)total * share);
+    if (g_budget_cap > 0 && g_budget_cap < b) b = g_budget_cap;
+    if (const char* e = getenv("XICSRT_WORKSPACE_BUDGET_MB")) { const long long v = atoll(e); if (v > 0 && ((size_t)v << 20) < b) b = (size_t)v << 20; }
+    if (b < (1ull << 20)) b = 1ull << 20;
+    return b;
+}
+#define XRT_ST_BUDGET   budget_of(XRT_ST_BUDGET_MAX, 0.40)
+#define XRT_CAND_BUDGET budget_of(XRT_CAND_BUDGET_MAX, 0.20)
 static int staged_slots_for(int n_runs, size_t per_slot_bytes, int per_cu)
 {
     size_t s = (size_t)XRT_ST_SLOTS * (size_t)per_cu;
@@ -3026,9 +3058,13 @@ static SegPlan plan_segments(const xrt_scene_t* sc, int n_runs)
     const int64_t N = sc->source.intensity;
     const bool gauss = gauss_prepared(sc->source);
     int want = 0, want_sub = 0;                 // units per run, parts per segment (0: by the cost model)
+    // (up to 512 runs: two units per run and more fill the chip's 1024 workgroup slots; round 3 stopped at 255, and 256 - 511
+    //  runs left half of the slots empty)
+    int seg_below = 513;
+    if (const char* e = getenv("XICSRT_SEG_BELOW")) { const int v = atoi(e); if (v >= 1) seg_below = v; }
     int64_t min_len = 4096;                     // below this the set-up of a unit outweighs its rays
     if (const char* e = getenv("XICSRT_SEGMENTS")) { want = atoi(e); want_sub = 1; min_len = XRT_TILE; }
-    else if (n_runs < 256) {
+    else if (n_runs < seg_below) {
         // one round of units, all resident together and of one size: as many as workgroups fit on the chip (a second
         // round for a few units more would double the time), four per CU (two for the mesh / local-frame variant)
         int target = 256 * ((needs_ext(sc) && !msplit) ? 2 : 4);
@@ -3137,7 +3173,6 @@ static size_t seg_bytes(const xrt_scene_t* sc, int n_runs)
 }
 // One-pass segmented runs park every unit's Bragg candidates in HBM: per run and ray of capacity 7 doubles, the ray
 // index and the hit face (64 B).  At the end of the workspace; beyond the budget the two-pass route is taken.
-#define XRT_CAND_BUDGET      (48ull << 30)
 #define XRT_CAND_BUDGET_TAIL (2ull << 30)       // for the < 256 runs an unsegmented launch leaves to a second pass
 static size_t cand_capacity(const xrt_scene_t* sc) { return ((size_t)(sc->source.intensity > 0 ? sc->source.intensity : 1) + 255) & ~(size_t)255; }
 static size_t mesh_split_off_aux(const xrt_scene_t* sc, int n_runs) { return al256((size_t)n_runs * cand_capacity(sc) * 80); }
@@ -3148,9 +3183,11 @@ static size_t cand_bytes(const xrt_scene_t* sc, int n_runs, size_t budget)
     const SegPlan p = plan_segments(sc, n_runs);
     if (!seg_active(p) || bragg_element(sc) < 0 || env_on("XICSRT_SEG_TWO_PASS")) return 0;
     if (p.mesh_split) {
-        // split phases: 10 doubles (+ the normal) and the face per ray, the rays left alive per 64 and per unit; twice the budget
+        // split phases: 10 doubles (+ the normal) and the face per ray, the rays left alive per 64 and per unit.  (A call whose
+        // runs would take more than the budget goes through them in batches, mesh_batch_runs; what is left over the budget
+        // here is a single run of > 6e8 rays.)
         const size_t b = mesh_split_off_unit_alive(sc, n_runs) + al256(sizeof(uint32_t) * (size_t)n_runs * (size_t)p.n_seg * (size_t)p.n_sub) + 256;
-        return b <= 2 * budget ? b : 0;
+        return b <= budget ? b : 0;
     }
     if (p.n_seg * p.n_sub <= 1) return 0;
     const size_t b = al256((size_t)n_runs * cand_capacity(sc) * 64) + 256;
@@ -3209,10 +3246,38 @@ static int image_rep_end(const xrt_scene_t* sc, char* ws, int n_runs, const KArg
     return 0;
 }
 static bool tail_split_possible(const xrt_scene_t* sc);
+// A mesh crystal's launches park 84 bytes per ray of capacity between them: a call whose runs would take more than the budget
+// goes through them in equal batches (every batch a call of its own over the same workspace: the sums are sums).  A batch of
+// fewer than 1024 runs is cut into work units by plan_segments (up to 512 runs), so a batch that cannot hold 1024 runs holds
+// at most 512.  Returns the runs per batch (n_runs: no batches).
+static bool mesh_split_ok(const xrt_scene_t* sc);
+static int mesh_batch_runs(const xrt_scene_t* sc, int n_runs)
+{
+    if (n_runs < 2 || needs_staged(sc) || !mesh_split_ok(sc)) return n_runs;
+    const size_t budget = XRT_CAND_BUDGET;
+    const size_t per_run = cand_capacity(sc) * 84 + cand_capacity(sc) / 16 + 64;
+    if (per_run * (size_t)n_runs + (1ull << 20) <= budget) return n_runs;
+    long long most = (long long)((budget - (budget < (2ull << 20) ? 0 : (1ull << 20))) / per_run);
+    if (most < 1) return n_runs;                    // (a single run beyond the budget: cand_bytes picks the route)
+    if (most < 1024 && most > 512) most = 512;
+    if (most >= n_runs) return n_runs;
+    const int n_batches = (int)((n_runs + most - 1) / most);
+    return (n_runs + n_batches - 1) / n_batches;
+}
 extern "C" size_t xrt_workspace_bytes(const xrt_scene_t* sc, int32_t n_runs)
 {
     if (!sc || n_runs < 0) return 0;
     if (n_runs < 1) n_runs = 1;
+    {
+        const int per = mesh_batch_runs(sc, n_runs);
+        if (per < n_runs) {
+            // the batches' layouts: `per` runs, and what is left for the last one
+            const int last = n_runs - (n_runs - 1) / per * per;
+            size_t need = ws_base_bytes(sc, per) + cand_bytes(sc, per, XRT_CAND_BUDGET);
+            const size_t b = ws_base_bytes(sc, last) + cand_bytes(sc, last, XRT_CAND_BUDGET);
+            return b > need ? b : need;
+        }
+    }
     size_t need = ws_base_bytes(sc, n_runs) + cand_bytes(sc, n_runs, XRT_CAND_BUDGET);
     // xrt_trace may leave the last < 256 runs of an unsegmented launch to a second pass over the same workspace,
     // which takes the segmented route with a layout of its own: the workspace holds that as well
@@ -4593,6 +4658,19 @@ extern "C" int xrt_trace(const xrt_scene_t* sc, const uint32_t* seeds, int32_t n
     // (the layout of this call; xrt_workspace_bytes() also covers the layouts of the possible second pass, which is
     //  checked when its run count is known -- a sweep over all of them here would cost a millisecond per call)
     if (workspace_bytes < ws_base_bytes(sc, n_runs)) return fail(-4, "%s", "workspace too small");
+    {   // a mesh crystal whose parked rays would not fit the budget: the runs in equal batches (mesh_batch_runs)
+        const int per = mesh_batch_runs(sc, n_runs);
+        if (per < n_runs) {
+            t_tail = -1;
+            for (int r0 = 0; r0 < n_runs; r0 += per) {
+                const int nb = (n_runs - r0) < per ? (n_runs - r0) : per;
+                if (workspace_bytes < ws_base_bytes(sc, nb) + cand_bytes(sc, nb, XRT_CAND_BUDGET)) return fail(-4, "%s", "workspace too small for a batch of runs");
+                st = trace_runs(sc, seeds + r0, nb, n_iter, num_out, images, workspace, workspace_bytes, stream_, r0 == 0);
+                if (st) return st;
+            }
+            return 0;
+        }
+    }
     // (see t_tail: the unsegmented launch may leave the last < 256 runs to a second pass over the same workspace)
     // (a second pass costs about a millisecond of set-up: only where a run takes longer than that)
     t_tail = tail_split_possible(sc) ? 0 : -1;
@@ -4980,6 +5058,8 @@ extern "C" uint32_t xrt_last_path(int32_t reset)
 }
 
 extern "C" size_t xrt_status_offset(void) { return XRT_WS_STATUS_BYTE; }
+
+extern "C" void xrt_set_workspace_budget(size_t bytes) { g_budget_cap = bytes; }
 
 extern "C" int xrt_check(void* workspace, void* stream_)
 {

@@ -262,7 +262,19 @@ class DeviceTrace:
         if need is None:
             need = self._ws_need[key] = int(self.lib.xrt_workspace_bytes(self.flat.byref(), n_runs))
         if self._ws is None or self._ws.numel() < need:
-            self._ws = self.torch.empty(max(need, 16), dtype=self.torch.uint8, device=self.dev)
+            self._ws = None
+            try:
+                self._ws = self.torch.empty(max(need, 16), dtype=self.torch.uint8, device=self.dev)
+            except self.torch.OutOfMemoryError:
+                # The big regions of a workspace are sized to budgets meant for a 288 GB part (include/xicsrt_hip.h,
+                # xrt_set_workspace_budget); on a card that is shared, or smaller, the library is told what there is and
+                # asked again: it then takes the runs in batches or a route that parks less.
+                self.torch.cuda.empty_cache()
+                free, _ = self.torch.cuda.mem_get_info(self.dev)
+                self.lib.xrt_set_workspace_budget(max(int(free * 0.6), 1 << 20))
+                self._ws_need.clear()
+                need = self._ws_need[key] = int(self.lib.xrt_workspace_bytes(self.flat.byref(), n_runs))
+                self._ws = self.torch.empty(max(need, 16), dtype=self.torch.uint8, device=self.dev)
         return self._ws, need
 
     def trace(self, seeds, n_iter, keep_images=True):
