@@ -423,6 +423,7 @@ int xrt_selftest_div3(const double* num, const double* den, int64_t n, uint64_t*
 #define XRT_PATH_LDS_BINS     256u   /* fused kernel with the pixel bins pre-aggregated in LDS (image-heavy scenes without a Bragg test) */
 #define XRT_PATH_ONE_PASS     512u   /* segmented runs in one pass: Bragg candidates parked in HBM, stream offsets by look-back */
 #define XRT_PATH_MESH_SPLIT   1024u  /* a mesh crystal: first phase, the rest of the mesh intersection per parked ray, second phase as three launches */
+#define XRT_PATH_MESH_FANS    2048u  /* ... the second pass over the faces around the nearest point first from that point's fan, the list walk for the rays left over */
 uint32_t xrt_last_path(int32_t reset);
 
 /* np.random.shuffle(np.arange(n))[:m] of numpy's legacy generator (host only, no device): what

@@ -203,7 +203,7 @@ def test_segmented_runs_equal_reference(name, segments, route, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('route', ['split', 'split_tables_in_global', 'split_every_face', 'split_batches', 'fused'])
+@pytest.mark.parametrize('route', ['split', 'split_tables_in_global', 'split_every_face', 'split_batches', 'split_list_walk', 'fused'])
 @pytest.mark.parametrize('name', ['E_cfg5_mesh_flat_1e5', 'E_cfg5_mesh_interp_1e5', 'E_mesh_interp_counts', 'E_mesh_norefine_counts',
                                   'E_mesh_81_coarse17_counts'])
 def test_mesh_crystal_routes_equal_reference(name, route, monkeypatch):
@@ -218,12 +218,17 @@ def test_mesh_crystal_routes_equal_reference(name, route, monkeypatch):
     if route == 'split_every_face':
         monkeypatch.setenv('XICSRT_NO_DIR_GRID', '1')
     cfg, gold = helpers.load_golden(name)
+    if route == 'split_list_walk':                                  # without the fans: every parked ray walks its point's face list
+        monkeypatch.setenv('XICSRT_NO_MESH_FANS', '1')
     config, elements, flat = helpers.build(cfg)
     if route == 'split_batches':                                    # a budget that holds one of the two runs: batches of runs
         cap = (flat.n_rays + 255) // 256 * 256
         whole = capi.lib().xrt_workspace_bytes(flat.byref(), 2)
-        monkeypatch.setenv('XICSRT_WORKSPACE_BUDGET_MB', str(int(1.6 * (cap * 84 + cap // 16)) // (1 << 20) + 1))
-        assert capi.lib().xrt_workspace_bytes(flat.byref(), 2) < whole - cap * 60
+        for mb in range(int(2 * cap * 100) // (1 << 20) + 2, 0, -1):       # (56 - 96 bytes per parked ray, by the mesh and the source)
+            monkeypatch.setenv('XICSRT_WORKSPACE_BUDGET_MB', str(mb))
+            if capi.lib().xrt_workspace_bytes(flat.byref(), 2) < whole - cap * 40:
+                break
+        assert capi.lib().xrt_workspace_bytes(flat.byref(), 2) < whole - cap * 40
     g = config['general']
     seeds = xrt.run_seeds(g['random_seed'], g['number_of_runs'])
     capi.lib().xrt_last_path(1)
@@ -237,6 +242,10 @@ def test_mesh_crystal_routes_equal_reference(name, route, monkeypatch):
             assert np.array_equal(image[nm].astype(np.int64), gold['image/' + nm]), nm
     path = capi.lib().xrt_last_path(1)
     assert bool(path & capi.PATH_MESH_SPLIT) == (route != 'fused'), (path, route)
+    if route in ('split_list_walk', 'split_tables_in_global', 'fused') or name in ('E_mesh_norefine_counts', 'E_mesh_81_coarse17_counts'):
+        assert not (path & capi.PATH_MESH_FANS), (path, route)          # (no coarse level / tables beyond the LDS: no fans)
+    else:
+        assert path & capi.PATH_MESH_FANS, (path, route)
 
 
 @pytest.mark.gpu

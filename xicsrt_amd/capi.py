@@ -24,6 +24,7 @@ PATH_PLASMA_SCOUT = 128
 PATH_LDS_BINS = 256
 PATH_ONE_PASS = 512
 PATH_MESH_SPLIT = 1024
+PATH_MESH_FANS = 2048
 
 _lib = None
 

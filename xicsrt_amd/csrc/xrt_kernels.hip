@@ -110,6 +110,7 @@ struct KSource {
 typedef const XRT_G1 double*  gdp;
 typedef const XRT_G1 int32_t* gip;
 typedef double  d4v __attribute__((ext_vector_type(4)));
+typedef double  d2v __attribute__((ext_vector_type(2)));
 typedef int32_t i4v __attribute__((ext_vector_type(4)));
 struct KCellRec { double x, y, z; int32_t idx, next; };      // a point of an x-y bucket; next: chain inside the bucket, -1 ends it
 struct KFaceRec { double p0[3], p1[3], p2[3], n[3], area, pad[3]; };   // what mesh_intersect_2 reads of a face, 128 B
@@ -159,6 +160,15 @@ struct KMesh {               // device pointers, see xrt_mesh_t
     const uint16_t* lds_pf;         // [n_points][8], 0xffff: none
     const uint16_t* lds_fv;         // [n_faces][4] (the fourth is padding)
     int32_t n_cells, lds_bytes;
+    // The faces around a point as a fan (xrt_mesh_star_lds_kernel; null: not built).  Per point 24 16-bit numbers: [0] the
+    // entries of the fan (0: this point's rays take the list walk), [1..9] the cells of its spokes -- the other vertices of
+    // its faces, counter-clockwise in x-y, the first one again at the end when the fan is closed --, [10..17] the face
+    // between entry t and t + 1 (0xffff: none), [18] two bits per such face: which of (point, entry t, entry t + 1) is the
+    // face's own first vertex, [19] the point's own cell, [20..23] two floats: the slopes dz/dx, dz/dy of the fan's mean
+    // plane.  star_K, star_c2: see mesh_rest_star_lds.
+    const uint16_t* lds_star;
+    int32_t star_lds_bytes, star_pad;
+    double  star_K, star_c2;
 };
 
 struct KOptic {
@@ -190,6 +200,8 @@ struct KOptic {
     int32_t mesh_lds_bytes;             // host side: KMesh.lds_bytes of `mesh` (which launch finishes a split mesh intersection)
     int32_t mesh_dir_bytes;             // host side: LDS bytes of the mesh's direction grid (KMesh.dg_n), 0: none
     int32_t mesh_ct_lds_bytes;          // host side: bytes of the mesh's Clough-Tocher vertex table when it fits the LDS (xrt_mesh_ct_lds_kernel), else 0
+    int32_t mesh_star_lds_bytes;        // host side: KMesh.star_lds_bytes of `mesh` (0: no fans, the list walk for every parked ray)
+    int32_t pad_star;
 };
 
 struct KScene {
@@ -1131,6 +1143,21 @@ struct KArgs {
     uint32_t dir_lds_bytes, pad_dir;    // SEG == 3: bytes of the direction grid's tables behind the workgroup's other LDS (0: none; KMesh.dg_n)
     uint32_t* batch_alive;              // [n_runs][cand_cap / 64]
     uint32_t* unit_alive;               // [n_runs][n_seg * n_sub], zero before the launch
+    // ... a mesh whose faces are known as fans around its points (KMesh.lds_star): xrt_mesh_star_lds_kernel settles the parked
+    // rays it can settle from the fan of the nearest point alone and lists the others per unit (slow_q: record numbers within
+    // the unit, unit_slow: how many); the launch that walks the face lists then takes only those (slow_pass != 0)
+    uint32_t* slow_q;                   // [n_runs][cand_cap]: the fan launch lists per 64 records (a wave: no atomics), slow_cnt how many;
+    uint32_t* slow_cnt;                 // [n_runs][cand_cap / 64]   xrt_mesh_slow_compact_kernel closes the gaps per unit (slow_q2, unit_slow),
+    uint32_t* slow_q2;                  // [n_runs][cand_cap]         and the list walk reads that (its slow_q = this slow_q2)
+    uint32_t* unit_slow;                // [n_runs][n_seg * n_sub]
+    uint32_t  slow_pass;
+    // What a parked ray's record holds between the launches.  A mesh that is not interpolated (split_interp == 0): its
+    // (local-frame) origin and direction [, wavelength] as the first phase left them, and in cand_aux the face its
+    // intersection ended on (XRT_CAND_DEAD: the ray is out) -- the hit point is not kept: the few rays the crystal reflects
+    // form it again from origin, direction and face (mesh_hit_point), and the normal is the face's.  An interpolated mesh
+    // (split_interp != 0): the hit point in place of the origin (its height from the interpolation) and the interpolated
+    // normal in components 6 - 8 (between the two middle launches component 6 holds the nearest point).
+    uint32_t  split_interp;
     unsigned long long* dbg;            // development: [units][8] wall-clock stamps of a unit's phases (null: none)
     // Pixel bins of the fused kernel: `images` may point to image_rep replicas, image_stride bins apart, which the library
     // sums into the caller's bins behind the last launch.  Scattered 8-byte atomics execute at the memory side, and all
@@ -1320,7 +1347,7 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
     size_t crun = 0;                // first ray-index / face word of the run
     // (blocks of 256 records, component-major inside a block: what a batch reads lies in one 12 - 14 KB stretch)
     // (split phases: + the surface normal at the hit point, components 6 - 8, which xrt_mesh_rest_kernel leaves)
-    const int q_wlc = SPLIT ? 9 : 6;
+    const int q_wlc = (SPLIT && args.split_interp) ? 9 : 6;
     const int q_ncomp = q_wlc + (q_has_wl ? 1 : 0);
     auto cand_store = [&](int64_t i, const V3& o, const V3& d, double wl, uint32_t id, int aux) __attribute__((always_inline)) {
         double* c = cbase + (i >> 8) * (int64_t)(q_ncomp * 256) + (i & 255);
@@ -1338,10 +1365,22 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
         id = HIST ? args.cand_id[crun + i] : 0u;
         aux = EXT ? (int)args.cand_aux[crun + i] : 0;
     };
-    auto cand_normal = [&](int64_t i) __attribute__((always_inline)) -> V3 {
-        const double* c = cbase + (i >> 8) * (int64_t)(q_ncomp * 256) + (i & 255);
+    // (split phases: the surface normal of a parked ray that is still there -- the face's, or the interpolated one with the
+    //  interpolated height, see KArgs.split_interp)
+    auto cand_normal = [&](int64_t i, int aux) __attribute__((always_inline)) -> V3 {
         V3 n;
-        n.x = c[6 * 256]; n.y = c[7 * 256]; n.z = c[8 * 256];
+        n.x = n.y = n.z = 0.0;
+        if constexpr (SPLIT) {
+            if ((uint32_t)aux == XRT_CAND_DEAD) return n;
+            if (args.split_interp) {
+                const double* c = cbase + (i >> 8) * (int64_t)(q_ncomp * 256) + (i & 255);
+                n.x = c[6 * 256]; n.y = c[7 * 256]; n.z = c[8 * 256];
+            } else {
+                MeshRef Mh = *(const XRT_C4 KMesh*)uniform_u64((uint64_t)SC.opt[be].mesh);
+                const gdp fn = Mh.faces_normal + 3 * (size_t)aux;
+                n.x = fn[0]; n.y = fn[1]; n.z = fn[2];
+            }
+        }
         return n;
     };
 
@@ -2234,7 +2273,7 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
                     pf_x.x = pf_x.y = pf_x.z = 0.0; pf_d = pf_x; pf_n = pf_x;
                     if (kb < ke && 64u * kb + (uint32_t)lane < n_candidates) {
                         cand_load(ray_lo + (int64_t)(64u * kb + (uint32_t)lane), pf_x, pf_d, pf_wl, pf_id, pf_aux);
-                        if constexpr (SPLIT) pf_n = cand_normal(ray_lo + (int64_t)(64u * kb + (uint32_t)lane));
+                        if constexpr (SPLIT) pf_n = cand_normal(ray_lo + (int64_t)(64u * kb + (uint32_t)lane), pf_aux);
                     }
                     for (uint32_t k = kb; k < ke; k++) {
                         const uint32_t c = 64u * k + (uint32_t)lane;
@@ -2257,7 +2296,7 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
 #ifndef XRT_ABL_NOLOAD
                         if (k + 1u < ke && c + 64u < n_candidates) {       // the wave's next batch
                             cand_load(ray_lo + (int64_t)(c + 64u), pf_x, pf_d, pf_wl, pf_id, pf_aux);
-                            if constexpr (SPLIT) pf_n = cand_normal(ray_lo + (int64_t)(c + 64u));
+                            if constexpr (SPLIT) pf_n = cand_normal(ray_lo + (int64_t)(c + 64u), pf_aux);
                         }
 #endif
                         // this batch's uniforms: words upos .. upos + 2 n_draws (np.random.uniform(0,1,n_live), optics/_InteractCrystal.py:189)
@@ -2292,6 +2331,11 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
                                     hist_write(args.hist, args.hmask, N, be + 1, id, xo, dd, ray.wl, false);
                                 }
                                 if (alive) {
+                                    if constexpr (SPLIT) {
+                                        // (a mesh that is not interpolated: the record holds the ray's origin -- its hit point on the
+                                        //  face, formed as the middle launches formed it)
+                                        if (!args.split_interp) X = mesh_hit_point(op.mesh, baux, ray);
+                                    }
                                     ray.o = X;
                                     double dt = dot_e(ray.d, nrm);
                                     ray.d.x = ray.d.x - 2.0 * (dt * nrm.x);
@@ -2428,7 +2472,8 @@ void xrt_mesh_rest_kernel(const KScene* __restrict__ scene_g, const KArgs args, 
 {
     const KScene* scl = scene_fresh(scene_g);
     const uint32_t unit = blockIdx.x / blocks_per_unit, blk = blockIdx.x - unit * blocks_per_unit;
-    const uint32_t n_unit = uni32(args.unit_flag[unit]) - 1u;
+    // (slow_pass: only the rays xrt_mesh_star_lds_kernel listed, see KArgs.slow_q)
+    const uint32_t n_unit = args.slow_pass ? uni32(args.unit_slow[unit]) : uni32(args.unit_flag[unit]) - 1u;
     if (256u * blk >= n_unit) return;
     const uint32_t upr = (uint32_t)args.n_seg * (uint32_t)args.n_sub;
     const uint32_t run = unit / upr, uidx = unit - run * upr;
@@ -2439,11 +2484,13 @@ void xrt_mesh_rest_kernel(const KScene* __restrict__ scene_g, const KArgs args, 
     int64_t ray_lo = seg_lo + (int64_t)sub * args.sub_len;
     if (ray_lo > seg_hi) ray_lo = seg_hi;
     const bool q_has_wl = !(SRC.wavelength_dist == XRT_WL_CONST && !SRC.has_velocity);
-    const int q_ncomp = 9 + (q_has_wl ? 1 : 0);
+    const int q_ncomp = (args.split_interp ? 9 : 6) + (q_has_wl ? 1 : 0);
     const size_t crun = (size_t)run * (size_t)args.cand_cap;
-    const int64_t i = ray_lo + (int64_t)(256u * blk + (uint32_t)threadIdx.x);
-    double* c = args.cand + crun * (size_t)q_ncomp + (i >> 8) * (int64_t)(q_ncomp * 256) + (i & 255);
     const bool have = 256u * blk + (uint32_t)threadIdx.x < n_unit;
+    uint32_t kk = 256u * blk + (uint32_t)threadIdx.x;          // the record's number within its unit
+    if (args.slow_pass && have) kk = args.slow_q[crun + (size_t)ray_lo + kk];
+    const int64_t i = ray_lo + (int64_t)kk;
+    double* c = args.cand + crun * (size_t)q_ncomp + (i >> 8) * (int64_t)(q_ncomp * 256) + (i & 255);
     const KOptic& op = SC.opt[be];
     bool alive = false;
     if (have) {
@@ -2452,23 +2499,25 @@ void xrt_mesh_rest_kernel(const KScene* __restrict__ scene_g, const KArgs args, 
         const MeshHit h = mesh_rest_impl<false>(op.mesh, c[0 * 256], c[1 * 256], c[2 * 256], c[3 * 256], c[4 * 256], c[5 * 256], face, &idx);
         V3 X;
         X.x = h.x; X.y = h.y; X.z = h.z;
+        // (what is left of the ray: the face it ended on, or XRT_CAND_DEAD -- see KArgs.split_interp)
         if constexpr (DEFER) {
             if (h.hit != 0) {
                 c[0 * 256] = X.x; c[1 * 256] = X.y; c[2 * 256] = X.z;
-                c[6 * 256] = __hiloint2double(0, idx);
-                args.cand_aux[crun + (size_t)i] = (uint32_t)h.aux;          // (the face that was hit: where the interpolation's walk starts)
-            } else args.cand_aux[crun + (size_t)i] = XRT_CAND_DEAD;
+                c[6 * 256] = __hiloint2double(0, idx);          // (the nearest point: where the interpolation's walk may start)
+            }
+            args.cand_aux[crun + (size_t)i] = h.hit != 0 ? (uint32_t)h.aux : XRT_CAND_DEAD;
         } else {
             alive = (h.hit != 0) && check_bounds<true>(op, X);
-            if (alive) {
-                const V3 nrm = mesh_normal_impl<false>(op.mesh, X.x, X.y, h.aux);
-                c[0 * 256] = X.x; c[1 * 256] = X.y; c[2 * 256] = X.z;
-                c[6 * 256] = nrm.x; c[7 * 256] = nrm.y; c[8 * 256] = nrm.z;
-            } else args.cand_aux[crun + (size_t)i] = XRT_CAND_DEAD;
+            args.cand_aux[crun + (size_t)i] = alive ? (uint32_t)h.aux : XRT_CAND_DEAD;
         }
     }
     if constexpr (DEFER) return;
     const unsigned long long ab = __ballot(alive);
+    if (args.slow_pass) {       // (the listed rays lie anywhere in the unit: they add to what the first launch counted)
+        if (alive) atomicAdd(&args.batch_alive[((crun + (size_t)ray_lo) >> 6) + (kk >> 6)], 1u);
+        if (ab != 0ULL && (threadIdx.x & 63u) == 0u) atomicAdd(&args.unit_alive[unit], (uint32_t)__popcll(ab));
+        return;
+    }
     if ((threadIdx.x & 63u) == 0u) {
         const uint32_t n = (uint32_t)__popcll(ab);
         args.batch_alive[((crun + (size_t)ray_lo) >> 6) + 4u * blk + (threadIdx.x >> 6)] = n;
@@ -2515,12 +2564,13 @@ void xrt_mesh_rest_lds_kernel(const KScene* __restrict__ scene_g, const KArgs ar
     L.first = (const XRT_LDS3 double*)l_first;
     const int64_t N = SRC.n_rays;
     const bool q_has_wl = !(SRC.wavelength_dist == XRT_WL_CONST && !SRC.has_velocity);
-    const int q_ncomp = 9 + (q_has_wl ? 1 : 0);
+    const int q_ncomp = (args.split_interp ? 9 : 6) + (q_has_wl ? 1 : 0);
     const uint32_t upr = (uint32_t)args.n_seg * (uint32_t)args.n_sub;
     const uint64_t items = (uint64_t)n_units * blocks_per_unit;             // (unit, block of 1024 rays)
     for (uint64_t it = blockIdx.x; it < items; it += gridDim.x) {
         const uint32_t unit = (uint32_t)(it / blocks_per_unit), blk = (uint32_t)(it - (uint64_t)unit * blocks_per_unit);
-        const uint32_t n_unit = uni32(args.unit_flag[unit]) - 1u;
+        // (slow_pass: only the rays xrt_mesh_star_lds_kernel listed, see KArgs.slow_q)
+        const uint32_t n_unit = args.slow_pass ? uni32(args.unit_slow[unit]) : uni32(args.unit_flag[unit]) - 1u;
         if (1024u * blk >= n_unit) continue;
         const uint32_t run = unit / upr, uidx = unit - run * upr;
         const uint32_t seg = uidx / (uint32_t)args.n_sub, sub = uidx - seg * (uint32_t)args.n_sub;
@@ -2530,9 +2580,11 @@ void xrt_mesh_rest_lds_kernel(const KScene* __restrict__ scene_g, const KArgs ar
         if (ray_lo > seg_hi) ray_lo = seg_hi;
         const size_t crun = (size_t)run * (size_t)args.cand_cap;
         const uint32_t k = 1024u * blk + (uint32_t)tid;
-        const int64_t i = ray_lo + (int64_t)k;
-        double* c = args.cand + crun * (size_t)q_ncomp + (i >> 8) * (int64_t)(q_ncomp * 256) + (i & 255);
         const bool have = k < n_unit;
+        uint32_t kk = k;                                        // the record's number within its unit
+        if (args.slow_pass && have) kk = args.slow_q[crun + (size_t)ray_lo + k];
+        const int64_t i = ray_lo + (int64_t)kk;
+        double* c = args.cand + crun * (size_t)q_ncomp + (i >> 8) * (int64_t)(q_ncomp * 256) + (i & 255);
         bool alive = false;
         if (have) {
             const int face = (int)args.cand_aux[crun + (size_t)i];
@@ -2546,23 +2598,206 @@ void xrt_mesh_rest_lds_kernel(const KScene* __restrict__ scene_g, const KArgs ar
                 if (h.hit != 0) {
                     c[0 * 256] = X.x; c[1 * 256] = X.y; c[2 * 256] = X.z;
                     c[6 * 256] = __hiloint2double(0, idx);
-                    args.cand_aux[crun + (size_t)i] = (uint32_t)h.aux;          // (the face that was hit: where the interpolation's walk starts)
-                } else args.cand_aux[crun + (size_t)i] = XRT_CAND_DEAD;
+                }
+                args.cand_aux[crun + (size_t)i] = h.hit != 0 ? (uint32_t)h.aux : XRT_CAND_DEAD;
             } else {
                 alive = (h.hit != 0) && check_bounds<true>(op, X);
-                if (alive) {
-                    c[0 * 256] = X.x; c[1 * 256] = X.y; c[2 * 256] = X.z;
-                    c[6 * 256] = nrm.x; c[7 * 256] = nrm.y; c[8 * 256] = nrm.z;
-                } else args.cand_aux[crun + (size_t)i] = XRT_CAND_DEAD;
+                args.cand_aux[crun + (size_t)i] = alive ? (uint32_t)h.aux : XRT_CAND_DEAD;
             }
         }
         if constexpr (DEFER) continue;
         const unsigned long long ab = __ballot(alive);
+        if (args.slow_pass) {       // (the listed rays lie anywhere in the unit: they add to what the first launch counted)
+            if (alive) atomicAdd(&args.batch_alive[((crun + (size_t)ray_lo) >> 6) + (kk >> 6)], 1u);
+            if (ab != 0ULL && (tid & 63) == 0) atomicAdd(&args.unit_alive[unit], (uint32_t)__popcll(ab));
+            continue;
+        }
         if ((tid & 63) == 0 && 64u * (k >> 6) < ((n_unit + 63u) & ~63u)) {
             const uint32_t n = (uint32_t)__popcll(ab);
             args.batch_alive[((crun + (size_t)ray_lo) >> 6) + (k >> 6)] = n;
             if (n) atomicAdd(&args.unit_alive[unit], n);
         }
+    }
+}
+
+// The fan launch (KMesh.lds_star, mesh_rest_star_lds): the parked rays that one face of the nearest point's fan settles are
+// finished here -- DEFER as above --, the others keep their records untouched and are listed per unit for the launch that
+// walks the lists (xrt_mesh_rest_lds_kernel / xrt_mesh_rest_kernel with slow_pass).  Tables in LDS: the buckets of the
+// points (also the vertex table), the fans, the faces of the first pass.
+template <bool DEFER>
+__global__ __launch_bounds__(XRT_MESH_LDS_THREADS)
+void xrt_mesh_star_lds_kernel(const KScene* __restrict__ scene_g, const KArgs args, int be, uint32_t blocks_per_unit, uint32_t n_units, uint32_t units_lds)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const KScene* scl = scene_fresh(scene_g);
+    const KOptic& op = SC.opt[be];
+    const KMesh* Mp = op.mesh;
+    MeshRef M = *(const XRT_C4 KMesh*)uniform_u64((uint64_t)Mp);
+    const int tid = threadIdx.x;
+    const uint32_t nc = (uint32_t)M.n_cells, np = (uint32_t)M.n_points, n1 = (uint32_t)M.n_first + 1u;
+    d4v* l_cells = reinterpret_cast<d4v*>(lds_raw);
+    uint32_t* l_star = reinterpret_cast<uint32_t*>(l_cells + nc);              // [np][12] words
+    double* l_first = reinterpret_cast<double*>(l_star + 12u * np);
+    // (the units' ray counts, when they fit behind the tables: finding a wave's next block then costs LDS reads instead of a
+    //  round trip to memory per block looked at)
+    uint32_t* l_units = reinterpret_cast<uint32_t*>(l_first + 10u * n1);
+    {
+        const XRT_G1 d4v* g = M.cells;
+        for (uint32_t i = (uint32_t)tid; i < nc; i += XRT_MESH_LDS_THREADS) l_cells[i] = g[i];
+        const XRT_G1 uint32_t* gs = (const XRT_G1 uint32_t*)(uint64_t)M.lds_star;
+        for (uint32_t i = (uint32_t)tid; i < 12u * np; i += XRT_MESH_LDS_THREADS) l_star[i] = gs[i];
+        const XRT_G1 double* g1 = (const XRT_G1 double*)(uint64_t)M.first_rec;
+        for (uint32_t i = (uint32_t)tid; i < 10u * n1; i += XRT_MESH_LDS_THREADS) l_first[i] = g1[i];
+        for (uint32_t i = (uint32_t)tid; i < units_lds; i += XRT_MESH_LDS_THREADS) l_units[i] = args.unit_flag[i];
+    }
+    __syncthreads();
+    MeshStarLds L;
+    L.cells = (lcell)l_cells;
+    L.star = (const XRT_LDS3 uint16_t*)l_star;
+    L.first = (const XRT_LDS3 double*)l_first;
+    const int64_t N = SRC.n_rays;
+    const bool q_has_wl = !(SRC.wavelength_dist == XRT_WL_CONST && !SRC.has_velocity);
+    const int q_ncomp = (args.split_interp ? 9 : 6) + (q_has_wl ? 1 : 0);
+    const uint32_t upr = (uint32_t)args.n_seg * (uint32_t)args.n_sub;
+    const uint64_t items = (uint64_t)n_units * blocks_per_unit;             // (unit, block of 1024 rays)
+    // Two blocks per round: a block's records are read once, ~2 us after they are asked for, and sixteen waves per CU do not
+    // cover that; with the records of two blocks asked for up front the second block's arrive while the first is worked on.
+    struct Block { uint32_t unit, k, n_unit; size_t crun; int64_t ray_lo; double* c; bool have; };
+    auto locate = [&](uint64_t it, Block& B) __attribute__((always_inline)) -> uint64_t {
+        // the next item at or behind `it` with rays in it (none: returns `items`)
+        for (; it < items; it += gridDim.x) {
+            const uint32_t unit = (uint32_t)(it / blocks_per_unit), blk = (uint32_t)(it - (uint64_t)unit * blocks_per_unit);
+            const uint32_t n_unit = uni32(unit < units_lds ? l_units[unit] : args.unit_flag[unit]) - 1u;
+            if (1024u * blk >= n_unit) continue;
+            const uint32_t run = unit / upr, uidx = unit - run * upr;
+            const uint32_t seg = uidx / (uint32_t)args.n_sub, sub = uidx - seg * (uint32_t)args.n_sub;
+            const int64_t seg_lo = (int64_t)seg * args.seg_len;
+            const int64_t seg_hi = (seg_lo + args.seg_len < N) ? seg_lo + args.seg_len : N;
+            int64_t ray_lo = seg_lo + (int64_t)sub * args.sub_len;
+            if (ray_lo > seg_hi) ray_lo = seg_hi;
+            B.unit = unit; B.n_unit = n_unit; B.ray_lo = ray_lo;
+            B.crun = (size_t)run * (size_t)args.cand_cap;
+            B.k = 1024u * blk + (uint32_t)tid;
+            const int64_t i = ray_lo + (int64_t)B.k;
+            B.c = args.cand + B.crun * (size_t)q_ncomp + (i >> 8) * (int64_t)(q_ncomp * 256) + (i & 255);
+            B.have = B.k < n_unit;
+            return it;
+        }
+        B.have = false; B.unit = 0; B.k = 0; B.n_unit = 0; B.crun = 0; B.ray_lo = 0; B.c = args.cand;
+        return items;
+    };
+    auto work = [&](const Block& B, const double* r, int face) __attribute__((always_inline)) {
+        const uint32_t unit = B.unit, k = B.k, n_unit = B.n_unit;
+        const size_t crun = B.crun;
+        const int64_t ray_lo = B.ray_lo, i = ray_lo + (int64_t)k;
+        double* c = B.c;
+        bool alive = false, slow = false;
+        if (B.have) {
+            int idx;
+            V3 nrm;
+            nrm.x = nrm.y = nrm.z = 0.0;
+            const MeshHit h = mesh_rest_star_lds(Mp, L, r[0], r[1], r[2], r[3], r[4], r[5], face, idx, nrm, slow);
+            if (!slow) {
+                V3 X;
+                X.x = h.x; X.y = h.y; X.z = h.z;
+                if constexpr (DEFER) {
+                    c[0 * 256] = X.x; c[1 * 256] = X.y; c[2 * 256] = X.z;
+                    c[6 * 256] = __hiloint2double(0, idx);
+                    args.cand_aux[crun + (size_t)i] = (uint32_t)h.aux;
+                } else {
+                    alive = check_bounds<true>(op, X);
+                    args.cand_aux[crun + (size_t)i] = alive ? (uint32_t)h.aux : XRT_CAND_DEAD;
+                }
+            }
+        }
+        // the rays left for the list walk: their numbers within the unit
+#ifdef XRT_DEV_NO_SLOWQ
+        const unsigned long long sl = 0ULL;
+#else
+        const unsigned long long sl = __ballot(slow);
+#endif
+        // (per 64 records -- this wave's -- and without atomics: a counter per unit that every wave of the chip adds to and
+        //  waits for cost 4 ms of the launch's 27)
+        if (slow) args.slow_q[crun + (size_t)ray_lo + (k & ~63u) + __builtin_amdgcn_mbcnt_hi((uint32_t)(sl >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sl, 0u))] = k;
+        if ((tid & 63) == 0 && 64u * (k >> 6) < ((n_unit + 63u) & ~63u)) args.slow_cnt[((crun + (size_t)ray_lo) >> 6) + (k >> 6)] = (uint32_t)__popcll(sl);
+        if constexpr (!DEFER) {
+            const unsigned long long ab = __ballot(alive);
+            if ((tid & 63) == 0 && 64u * (k >> 6) < ((n_unit + 63u) & ~63u)) {
+                const uint32_t n = (uint32_t)__popcll(ab);
+                args.batch_alive[((crun + (size_t)ray_lo) >> 6) + (k >> 6)] = n;
+                if (n) atomicAdd(&args.unit_alive[unit], n);
+            }
+        }
+    };
+    uint64_t it = blockIdx.x;
+    for (;;) {
+        Block A, B;
+        const uint64_t ia = locate(it, A);
+        if (ia >= items) break;
+        const uint64_t ib = locate(ia + gridDim.x, B);
+        // both blocks' records: asked for here, used below
+        double ra[6], rb[6];
+        int fa = 0, fb = 0;
+#pragma unroll
+        for (int q = 0; q < 6; q++) { ra[q] = 0.0; rb[q] = 0.0; }
+        if (A.have) {
+#pragma unroll
+            for (int q = 0; q < 6; q++) ra[q] = A.c[q * 256];
+            fa = (int)args.cand_aux[A.crun + (size_t)(A.ray_lo + (int64_t)A.k)];
+        }
+        if (B.have) {
+#pragma unroll
+            for (int q = 0; q < 6; q++) rb[q] = B.c[q * 256];
+            fb = (int)args.cand_aux[B.crun + (size_t)(B.ray_lo + (int64_t)B.k)];
+        }
+        work(A, ra, fa);
+        if (ib < items) work(B, rb, fb);
+        it = ib + gridDim.x;
+    }
+}
+
+// The fan launch's lists (per 64 records of a unit) without their gaps: per unit one dense list for the launch that walks the
+// face lists, and its length.  A workgroup per unit, 256 runs of 64 records a step.
+__global__ __launch_bounds__(256)
+void xrt_mesh_slow_compact_kernel(const KScene* __restrict__ scene_g, const KArgs args, uint32_t n_units)
+{
+    __shared__ uint32_t part[256];
+    __shared__ uint32_t running;
+    const KScene* scl = scene_fresh(scene_g);
+    const int64_t N = SRC.n_rays;
+    const uint32_t upr = (uint32_t)args.n_seg * (uint32_t)args.n_sub;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+        const uint32_t n_unit = uni32(args.unit_flag[unit]) - 1u;
+        const uint32_t run = unit / upr, uidx = unit - run * upr;
+        const uint32_t seg = uidx / (uint32_t)args.n_sub, sub = uidx - seg * (uint32_t)args.n_sub;
+        const int64_t seg_lo = (int64_t)seg * args.seg_len;
+        const int64_t seg_hi = (seg_lo + args.seg_len < N) ? seg_lo + args.seg_len : N;
+        int64_t ray_lo = seg_lo + (int64_t)sub * args.sub_len;
+        if (ray_lo > seg_hi) ray_lo = seg_hi;
+        const size_t base = (size_t)run * (size_t)args.cand_cap + (size_t)ray_lo;
+        const uint32_t nb = (n_unit + 63u) >> 6;
+        if (tid == 0) running = 0u;
+        __syncthreads();
+        for (uint32_t b0 = 0; b0 < nb; b0 += 256u) {
+            const uint32_t b = b0 + tid;
+            const uint32_t cnt = b < nb ? args.slow_cnt[(base >> 6) + b] : 0u;
+            part[tid] = cnt;
+            __syncthreads();
+            for (uint32_t off = 1u; off < 256u; off <<= 1) {
+                const uint32_t v = tid >= off ? part[tid - off] : 0u;
+                __syncthreads();
+                part[tid] += v;
+                __syncthreads();
+            }
+            const uint32_t at = running + part[tid] - cnt;
+            for (uint32_t j = 0; j < cnt; j++) args.slow_q2[base + at + j] = args.slow_q[base + 64u * b + j];
+            __syncthreads();
+            if (tid == 255u) running += part[255];
+            __syncthreads();
+        }
+        if (tid == 0) args.unit_slow[unit] = running;
+        __syncthreads();
     }
 }
 
@@ -2584,7 +2819,7 @@ void xrt_mesh_ct_kernel(const KScene* __restrict__ scene_g, const KArgs args, in
     int64_t ray_lo = seg_lo + (int64_t)sub * args.sub_len;
     if (ray_lo > seg_hi) ray_lo = seg_hi;
     const bool q_has_wl = !(SRC.wavelength_dist == XRT_WL_CONST && !SRC.has_velocity);
-    const int q_ncomp = 9 + (q_has_wl ? 1 : 0);
+    const int q_ncomp = (args.split_interp ? 9 : 6) + (q_has_wl ? 1 : 0);
     const size_t crun = (size_t)run * (size_t)args.cand_cap;
     const int64_t i = ray_lo + (int64_t)(256u * blk + (uint32_t)threadIdx.x);
     double* c = args.cand + crun * (size_t)q_ncomp + (i >> 8) * (int64_t)(q_ncomp * 256) + (i & 255);
@@ -2637,7 +2872,7 @@ void xrt_mesh_ct_lds_kernel(const KScene* __restrict__ scene_g, const KArgs args
     const XRT_LDS3 double* lv = (const XRT_LDS3 double*)l_v;
     const int64_t N = SRC.n_rays;
     const bool q_has_wl = !(SRC.wavelength_dist == XRT_WL_CONST && !SRC.has_velocity);
-    const int q_ncomp = 9 + (q_has_wl ? 1 : 0);
+    const int q_ncomp = (args.split_interp ? 9 : 6) + (q_has_wl ? 1 : 0);
     const uint32_t upr = (uint32_t)args.n_seg * (uint32_t)args.n_sub;
     const uint64_t items = (uint64_t)n_units * blocks_per_unit;
     for (uint64_t it = blockIdx.x; it < items; it += gridDim.x) {
@@ -3175,9 +3410,23 @@ static size_t seg_bytes(const xrt_scene_t* sc, int n_runs)
 // index and the hit face (64 B).  At the end of the workspace; beyond the budget the two-pass route is taken.
 #define XRT_CAND_BUDGET_TAIL (2ull << 30)       // for the < 256 runs an unsegmented launch leaves to a second pass
 static size_t cand_capacity(const xrt_scene_t* sc) { return ((size_t)(sc->source.intensity > 0 ? sc->source.intensity : 1) + 255) & ~(size_t)255; }
-static size_t mesh_split_off_aux(const xrt_scene_t* sc, int n_runs) { return al256((size_t)n_runs * cand_capacity(sc) * 80); }
+// doubles of a parked ray's record between the launches of a split trace (KArgs.split_interp): origin, direction
+// [, interpolated normal] [, wavelength]
+static int split_comps(const xrt_scene_t* sc)
+{
+    const int be = bragg_element(sc);
+    const bool interp = be >= 0 && sc->optics[be].mesh && sc->optics[be].mesh->interpolate;
+    const bool has_wl = !(sc->source.wavelength_dist == XRT_WL_CONST && !sc->source.has_velocity);
+    return (interp ? 9 : 6) + (has_wl ? 1 : 0);
+}
+static size_t mesh_split_off_aux(const xrt_scene_t* sc, int n_runs) { return al256((size_t)n_runs * cand_capacity(sc) * 8 * (size_t)split_comps(sc)); }
 static size_t mesh_split_off_batch_alive(const xrt_scene_t* sc, int n_runs) { return mesh_split_off_aux(sc, n_runs) + al256((size_t)n_runs * cand_capacity(sc) * 4); }
 static size_t mesh_split_off_unit_alive(const xrt_scene_t* sc, int n_runs) { return mesh_split_off_batch_alive(sc, n_runs) + al256((size_t)n_runs * (cand_capacity(sc) / 64) * 4); }
+// (behind the units' counts: the rays the fan launch leaves to the list walk, per unit, and how many -- KArgs.slow_q)
+static size_t mesh_split_off_slow_q(const xrt_scene_t* sc, int n_runs, const SegPlan& p) { return mesh_split_off_unit_alive(sc, n_runs) + al256(sizeof(uint32_t) * (size_t)n_runs * (size_t)p.n_seg * (size_t)p.n_sub); }
+static size_t mesh_split_off_slow_cnt(const xrt_scene_t* sc, int n_runs, const SegPlan& p) { return mesh_split_off_slow_q(sc, n_runs, p) + al256((size_t)n_runs * cand_capacity(sc) * 4); }
+static size_t mesh_split_off_slow_q2(const xrt_scene_t* sc, int n_runs, const SegPlan& p) { return mesh_split_off_slow_cnt(sc, n_runs, p) + al256((size_t)n_runs * (cand_capacity(sc) / 64) * 4); }
+static size_t mesh_split_off_unit_slow(const xrt_scene_t* sc, int n_runs, const SegPlan& p) { return mesh_split_off_slow_q2(sc, n_runs, p) + al256((size_t)n_runs * cand_capacity(sc) * 4); }
 static size_t cand_bytes(const xrt_scene_t* sc, int n_runs, size_t budget)
 {
     const SegPlan p = plan_segments(sc, n_runs);
@@ -3186,7 +3435,7 @@ static size_t cand_bytes(const xrt_scene_t* sc, int n_runs, size_t budget)
         // split phases: 10 doubles (+ the normal) and the face per ray, the rays left alive per 64 and per unit.  (A call whose
         // runs would take more than the budget goes through them in batches, mesh_batch_runs; what is left over the budget
         // here is a single run of > 6e8 rays.)
-        const size_t b = mesh_split_off_unit_alive(sc, n_runs) + al256(sizeof(uint32_t) * (size_t)n_runs * (size_t)p.n_seg * (size_t)p.n_sub) + 256;
+        const size_t b = mesh_split_off_unit_slow(sc, n_runs, p) + al256(sizeof(uint32_t) * (size_t)n_runs * (size_t)p.n_seg * (size_t)p.n_sub) + 256;
         return b <= budget ? b : 0;
     }
     if (p.n_seg * p.n_sub <= 1) return 0;
@@ -3246,7 +3495,7 @@ static int image_rep_end(const xrt_scene_t* sc, char* ws, int n_runs, const KArg
     return 0;
 }
 static bool tail_split_possible(const xrt_scene_t* sc);
-// A mesh crystal's launches park 84 bytes per ray of capacity between them: a call whose runs would take more than the budget
+// A mesh crystal's launches park 60 - 92 bytes per ray of capacity between them (split_comps): a call whose runs would take more than the budget
 // goes through them in equal batches (every batch a call of its own over the same workspace: the sums are sums).  A batch of
 // fewer than 1024 runs is cut into work units by plan_segments (up to 512 runs), so a batch that cannot hold 1024 runs holds
 // at most 512.  Returns the runs per batch (n_runs: no batches).
@@ -3255,7 +3504,7 @@ static int mesh_batch_runs(const xrt_scene_t* sc, int n_runs)
 {
     if (n_runs < 2 || needs_staged(sc) || !mesh_split_ok(sc)) return n_runs;
     const size_t budget = XRT_CAND_BUDGET;
-    const size_t per_run = cand_capacity(sc) * 84 + cand_capacity(sc) / 16 + 64;
+    const size_t per_run = cand_capacity(sc) * (8 * (size_t)split_comps(sc) + 12) + cand_capacity(sc) / 8 + 64;
     if (per_run * (size_t)n_runs + (1ull << 20) <= budget) return n_runs;
     long long most = (long long)((budget - (budget < (2ull << 20) ? 0 : (1ull << 20))) / per_run);
     if (most < 1) return n_runs;                    // (a single run beyond the budget: cand_bytes picks the route)
@@ -3506,6 +3755,7 @@ static int upload_meshes(const xrt_scene_t* sc, char* ws, int n_runs, KScene* ks
         ks->opt[e].mesh_lds_bytes = 0;
         ks->opt[e].mesh_dir_bytes = 0;
         ks->opt[e].mesh_ct_lds_bytes = 0;
+        ks->opt[e].mesh_star_lds_bytes = 0;
         if (sc->optics[e].shape != XRT_SHAPE_MESH) continue;
         // The packed tables are host temporaries, copied synchronously; an earlier call on `stream` may still be
         // reading this part of the workspace (with another layout): wait for it first.  (Mesh scenes only; every other
@@ -3969,6 +4219,139 @@ static int upload_meshes(const xrt_scene_t* sc, char* ws, int n_runs, KScene* ks
                         k.lds_fv = (const uint16_t*)put(fv.data(), fv.size() * 2);
                         k.lds_bytes = (int32_t)lds_need;
                     }
+                    // ---- the faces around every point as a fan (KMesh.lds_star, mesh_rest_star_lds) ------------------
+                    const size_t star_need = cells.size() * sizeof(KCellRec) + P * 48 + (n_first + 1) * 80 + 64;
+                    if (all && star_need <= XRT_MESH_LDS_MAX && !env_on("XICSRT_NO_MESH_FANS")) {
+                        auto sub = [](const double* a, const double* b, double* o) { o[0] = a[0] - b[0]; o[1] = a[1] - b[1]; o[2] = a[2] - b[2]; };
+                        auto crs = [](const double* a, const double* b, double* o) { o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0]; };
+                        auto dot = [](const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+                        auto len = [&](const double* a) { return sqrt(dot(a, a)); };
+                        // the smallest altitude, edge and sin(angle / 2) of the mesh's faces
+                        double h_min = HUGE_VAL, l_min = HUGE_VAL, s_min = 1.0;
+                        bool faces_ok = true;
+                        for (size_t i = 0; i < F && faces_ok; i++) {
+                            const double* v[3] = {m->p0 + 3 * i, m->p1 + 3 * i, m->p2 + 3 * i};
+                            double e[3][3], l[3], nrm[3];
+                            for (int j = 0; j < 3; j++) { sub(v[(j + 1) % 3], v[j], e[j]); l[j] = len(e[j]); }
+                            crs(e[0], e[1], nrm);
+                            const double a2 = len(nrm), lmax = fmax(l[0], fmax(l[1], l[2])), lmn = fmin(l[0], fmin(l[1], l[2]));
+                            faces_ok = std::isfinite(a2) && a2 > 0.0 && std::isfinite(lmax) && lmn > 0.0;
+                            if (!faces_ok) break;
+                            h_min = fmin(h_min, a2 / lmax); l_min = fmin(l_min, lmn);
+                            for (int j = 0; j < 3; j++) {           // the angle at vertex j + 1, between -e[j] and e[j + 1]
+                                const double cs = -dot(e[j], e[(j + 1) % 3]) / (l[j] * l[(j + 1) % 3]);
+                                const double half = sqrt(fmax(0.0, 0.5 * (1.0 - fmin(1.0, fmax(-1.0, cs)))));       // sin(angle / 2)
+                                s_min = fmin(s_min, half);
+                            }
+                        }
+                        const double starK = faces_ok ? 1e-10 / (h_min * l_min * s_min) : HUGE_VAL;
+                        if (std::isfinite(starK) && starK > 0.0 && starK < 1e-3) {
+                            std::vector<uint16_t> star(P * 24, 0);
+                            double spread = 0.0;
+                            size_t n_fans = 0;
+                            for (size_t i = 0; i < P; i++) {
+                                if (pslot[i] < 0) continue;
+                                const uint16_t cs = (uint16_t)pslot[i];
+                                const KCellRec& pc = cells[cs];
+                                int fl[8], nf = 0;
+                                for (int j = 0; j < 8; j++) if (pf16[8 * i + j] != 0xffff) fl[nf++] = pf16[8 * i + j];
+                                if (nf == 0) continue;
+                                struct Spoke { uint16_t slot; double ang; };
+                                std::vector<Spoke> sp;
+                                bool ok = true;
+                                for (int q = 0; q < nf && ok; q++) {
+                                    int own = 0;
+                                    for (int vtx = 0; vtx < 3; vtx++) {
+                                        const uint16_t sl = fv[4 * (size_t)fl[q] + vtx];
+                                        if (sl == cs) { own++; continue; }
+                                        bool seen = false;
+                                        for (const Spoke& t : sp) seen = seen || t.slot == sl;
+                                        if (!seen) sp.push_back({sl, atan2(cells[sl].y - pc.y, cells[sl].x - pc.x)});
+                                    }
+                                    ok = own == 1;
+                                    for (int r = 0; r < q && ok; r++) ok = fl[r] != fl[q];
+                                }
+                                const int ms = (int)sp.size();
+                                if (!ok || ms < 2 || ms > 9) continue;
+                                for (const Spoke& t : sp) ok = ok && std::isfinite(t.ang);
+                                if (!ok) continue;
+                                std::sort(sp.begin(), sp.end(), [](const Spoke& a, const Spoke& b) { return a.ang < b.ang; });
+                                // the face between consecutive spokes (counter-clockwise); every face of the point must be one
+                                std::vector<int> sect(ms, -1);
+                                int used = 0;
+                                for (int t = 0; t < ms; t++) {
+                                    const uint16_t sa = sp[t].slot, sb = sp[(t + 1) % ms].slot;
+                                    if (ms == 2 && t == 1) break;               // (two spokes: one sector)
+                                    for (int q = 0; q < nf; q++) {
+                                        const uint16_t* fq = &fv[4 * (size_t)fl[q]];
+                                        const bool ha = fq[0] == sa || fq[1] == sa || fq[2] == sa, hb = fq[0] == sb || fq[1] == sb || fq[2] == sb;
+                                        if (ha && hb && sa != sb) { if (sect[t] < 0) { sect[t] = fl[q]; used++; } else ok = false; }
+                                    }
+                                }
+                                if (!ok || used != nf) continue;
+                                // a sector with a face: counter-clockwise in x-y and narrower than pi; the fan's normals close together
+                                double nsum[3] = {0, 0, 0};
+                                std::vector<double> nrm((size_t)ms * 3, 0.0);
+                                const double pp[3] = {pc.x, pc.y, pc.z};
+                                for (int t = 0; t < ms && ok; t++) {
+                                    if (sect[t] < 0) continue;
+                                    const KCellRec &qa = cells[sp[t].slot], &qb = cells[sp[(t + 1) % ms].slot];
+                                    const double a[3] = {qa.x, qa.y, qa.z}, b[3] = {qb.x, qb.y, qb.z};
+                                    double e1[3], e2[3];
+                                    sub(a, pp, e1); sub(b, pp, e2);
+                                    double turn = sp[(t + 1) % ms].ang - sp[t].ang;
+                                    if (turn < 0.0) turn += 6.283185307179586;
+                                    crs(e1, e2, &nrm[3 * t]);
+                                    const double nl = len(&nrm[3 * t]);
+                                    ok = nrm[3 * t + 2] > 0.0 && turn > 1e-6 && turn < 3.1 && std::isfinite(nl) && nl > 0.0;
+                                    if (!ok) break;
+                                    for (int c = 0; c < 3; c++) { nrm[3 * t + c] /= nl; nsum[c] += nrm[3 * t + c]; }
+                                }
+                                if (!ok) continue;
+                                double worst = 0.0;
+                                for (int t = 0; t < ms; t++)
+                                    for (int u = t + 1; u < ms; u++)
+                                        if (sect[t] >= 0 && sect[u] >= 0) worst = fmax(worst, acos(fmin(1.0, fmax(-1.0, dot(&nrm[3 * t], &nrm[3 * u])))));
+                                if (!(worst < 0.2)) continue;
+                                // entries: a closed fan repeats its first spoke at the end; an open one starts behind a gap
+                                int start = 0;
+                                bool closed = true;
+                                for (int t = 0; t < ms; t++) if (sect[t] < 0) { closed = false; start = (t + 1) % ms; }
+                                if (ms == 2) { closed = false; start = 0; }
+                                const int n_ent = closed ? ms + 1 : ms;
+                                if (n_ent > 9) continue;
+                                uint16_t* rec = &star[24 * i];
+                                rec[0] = (uint16_t)n_ent;
+                                uint16_t codes = 0;
+                                for (int t = 0; t < n_ent; t++) rec[1 + t] = sp[(start + t) % ms].slot;
+                                for (int t = 0; t < 8; t++) rec[10 + t] = 0xffff;
+                                for (int t = 0; t + 1 < n_ent; t++) {
+                                    const int st = (start + t) % ms;
+                                    if (sect[st] < 0) continue;
+                                    rec[10 + t] = (uint16_t)sect[st];
+                                    const uint16_t v0 = fv[4 * (size_t)sect[st]];
+                                    const uint16_t code = v0 == cs ? 0 : (v0 == sp[st].slot ? 1 : 2);
+                                    codes |= (uint16_t)(code << (2 * t));
+                                }
+                                rec[18] = codes;
+                                rec[19] = cs;
+                                {   // the fan's mean plane through the point, z - z_p = gx (x - x_p) + gy (y - y_p), single precision
+                                    const float gx = (float)(-nsum[0] / nsum[2]), gy = (float)(-nsum[1] / nsum[2]);
+                                    if (!(std::isfinite(gx) && std::isfinite(gy))) { rec[0] = 0; continue; }
+                                    memcpy(&rec[20], &gx, 4);
+                                    memcpy(&rec[22], &gy, 4);
+                                }
+                                spread = fmax(spread, worst);
+                                n_fans++;
+                            }
+                            if (n_fans > 0) {
+                                k.lds_star = (const uint16_t*)put(star.data(), star.size() * 2);
+                                k.star_lds_bytes = (int32_t)star_need;
+                                k.star_K = starK;
+                                k.star_c2 = (2.0 * spread + 0.05) * (2.0 * spread + 0.05);
+                            }
+                        }
+                    }
                 }
             }
         }
@@ -3976,6 +4359,7 @@ static int upload_meshes(const xrt_scene_t* sc, char* ws, int n_runs, KScene* ks
         HIP_TRY(hipMemcpy(base, &k, sizeof(KMesh), hipMemcpyHostToDevice));
         ks->opt[e].mesh = reinterpret_cast<const KMesh*>(base);
         ks->opt[e].mesh_lds_bytes = k.lds_bytes;
+        ks->opt[e].mesh_star_lds_bytes = k.star_lds_bytes;
         ks->opt[e].mesh_ct_lds_bytes = (m->interpolate && (size_t)m->n_points * 96 + 64 <= 160u * 1024u && !env_on("XICSRT_NO_MESH_LDS"))
                                            ? (int32_t)((size_t)m->n_points * 96) : 0;
         ks->opt[e].mesh_dir_bytes = (k.dg_n > 0 && !k.dg_big) ? (int32_t)(((size_t)k.n_first + 1) * 96 + (size_t)k.dg_n * k.dg_n * 8) : 0;
@@ -4418,10 +4802,17 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
             a.cand_aux = reinterpret_cast<uint32_t*>(cb + mesh_split_off_aux(sc, n_runs));
             a.batch_alive = reinterpret_cast<uint32_t*>(cb + mesh_split_off_batch_alive(sc, n_runs));
             a.unit_alive = reinterpret_cast<uint32_t*>(cb + mesh_split_off_unit_alive(sc, n_runs));
+            a.slow_q = reinterpret_cast<uint32_t*>(cb + mesh_split_off_slow_q(sc, n_runs, plan));
+            a.slow_cnt = reinterpret_cast<uint32_t*>(cb + mesh_split_off_slow_cnt(sc, n_runs, plan));
+            a.slow_q2 = reinterpret_cast<uint32_t*>(cb + mesh_split_off_slow_q2(sc, n_runs, plan));
+            a.unit_slow = reinterpret_cast<uint32_t*>(cb + mesh_split_off_unit_slow(sc, n_runs, plan));
+            a.slow_pass = 0;
+            a.split_interp = (sc->optics[be].mesh && sc->optics[be].mesh->interpolate) ? 1u : 0u;
             a.cand_cap = (int64_t)cand_capacity(sc);
             a.unit_flag = d_cnt;
             HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(uint32_t) * (size_t)n_runs * (size_t)S * (size_t)M, stream));
             HIP_TRY(hipMemsetAsync(a.unit_alive, 0, sizeof(uint32_t) * (size_t)n_runs * (size_t)S * (size_t)M, stream));
+            HIP_TRY(hipMemsetAsync(a.unit_slow, 0, sizeof(uint32_t) * (size_t)n_runs * (size_t)S * (size_t)M, stream));
             g_paths |= XRT_PATH_ONE_PASS | XRT_PATH_MESH_SPLIT;
         } else
         if (one_pass) {
@@ -4496,6 +4887,27 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
             const unsigned long long items = (unsigned long long)n_runs * (unsigned long long)(S * M) * bpu4;
             const unsigned grid = (unsigned)(items < (unsigned long long)c_cus3 ? items : (unsigned long long)c_cus3);
             const uint32_t n_units = (uint32_t)(n_runs * S * M);
+            // a mesh with fans: what one face of the nearest point's fan settles first, the launch below for the rays left over
+            const int lds_st = ks.opt[be].mesh_star_lds_bytes;
+            if (lds_m > 0 && lds_st > 0) {
+                // (the units' counts behind the tables, as many as fit)
+                uint32_t units_lds = n_units;
+                if ((size_t)lds_st + 4 * (size_t)units_lds > 160u * 1024u) units_lds = (uint32_t)((160u * 1024u - (size_t)lds_st) / 4);
+                const size_t lds_su = (size_t)lds_st + 4 * (size_t)units_lds;
+                if (ct) {
+                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(xrt_mesh_star_lds_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_su));
+                    hipLaunchKernelGGL((xrt_mesh_star_lds_kernel<true>), dim3(grid), dim3(XRT_MESH_LDS_THREADS), lds_su, stream, device_scene(ws), am, be, bpu4, n_units, units_lds);
+                } else {
+                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(xrt_mesh_star_lds_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_su));
+                    hipLaunchKernelGGL((xrt_mesh_star_lds_kernel<false>), dim3(grid), dim3(XRT_MESH_LDS_THREADS), lds_su, stream, device_scene(ws), am, be, bpu4, n_units, units_lds);
+                }
+                HIP_TRY(hipGetLastError());
+                hipLaunchKernelGGL(xrt_mesh_slow_compact_kernel, dim3(n_units < 2048u ? n_units : 2048u), dim3(256), 0, stream, device_scene(ws), am, n_units);
+                HIP_TRY(hipGetLastError());
+                am.slow_pass = 1;
+                am.slow_q = am.slow_q2;
+                g_paths |= XRT_PATH_MESH_FANS;
+            }
             // up to the hit face (an interpolated mesh: the rest is the next launch's)
             if (lds_m > 0) {
                 if (ct) {
@@ -4510,6 +4922,7 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
             else
                 hipLaunchKernelGGL((xrt_mesh_rest_kernel<false>), dim3((unsigned)blocks), dim3(XRT_TILE), 0, stream, device_scene(ws), am, be, bpu);
             HIP_TRY(hipGetLastError());
+            am.slow_pass = 0;
             // interpolation, bounds, counts
             if (ct) {
                 if (lds_ct > 0) {
