@@ -622,6 +622,14 @@ def build_cases():
         c = _crystal('XicsrtOpticMeshToroidalCrystal', radius_major=1.0, radius_minor=0.2,
                      mesh_size=[41, 41], mesh_interpolate=interp, **_BRAGG)
         add('E_cfg5_mesh_%s_1e5' % ('interp' if interp else 'flat'), 'counts', cfg_three(100000, c, seed=84, runs=2))
+    # ... and the same geometry with a rocking curve wide enough to put >= 1e3 rays per 1e5 on the detector (cfg5's own curve of
+    # 48 urad reflects none or a handful from a faceted surface: its goldens hold the pixel path to very little), the fine mesh
+    # searched directly as well
+    for tag, extra in (('flat', dict(mesh_interpolate=False)), ('interp', dict(mesh_interpolate=True)),
+                       ('norefine', dict(mesh_refine=False))):
+        c = _crystal('XicsrtOpticMeshToroidalCrystal', radius_major=1.0, radius_minor=0.2, mesh_size=[41, 41],
+                     **dict(_BRAGG, rocking_fwhm=2e-2), **extra)
+        add('E_cfg5_wide_%s_1e5' % tag, 'counts', cfg_three(100000, c, seed=85, runs=2))
     return C
 
 

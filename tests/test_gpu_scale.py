@@ -205,7 +205,7 @@ def test_segmented_runs_equal_reference(name, segments, route, monkeypatch):
 @pytest.mark.gpu
 @pytest.mark.parametrize('route', ['split', 'split_tables_in_global', 'split_every_face', 'split_batches', 'split_list_walk', 'fused'])
 @pytest.mark.parametrize('name', ['E_cfg5_mesh_flat_1e5', 'E_cfg5_mesh_interp_1e5', 'E_mesh_interp_counts', 'E_mesh_norefine_counts',
-                                  'E_mesh_81_coarse17_counts'])
+                                  'E_mesh_81_coarse17_counts', 'E_cfg5_wide_flat_1e5', 'E_cfg5_wide_interp_1e5', 'E_cfg5_wide_norefine_1e5'])
 def test_mesh_crystal_routes_equal_reference(name, route, monkeypatch):
     """A mesh crystal that makes the Bragg test goes through three launches -- rays up to the first pass over the faces
     (behind a point source: through the grid over the directions), the rest of ShapeMesh.intersect per parked ray (small
@@ -242,7 +242,8 @@ def test_mesh_crystal_routes_equal_reference(name, route, monkeypatch):
             assert np.array_equal(image[nm].astype(np.int64), gold['image/' + nm]), nm
     path = capi.lib().xrt_last_path(1)
     assert bool(path & capi.PATH_MESH_SPLIT) == (route != 'fused'), (path, route)
-    if route in ('split_list_walk', 'split_tables_in_global', 'fused') or name in ('E_mesh_norefine_counts', 'E_mesh_81_coarse17_counts'):
+    if route in ('split_list_walk', 'split_tables_in_global', 'fused') or name in ('E_mesh_norefine_counts', 'E_mesh_81_coarse17_counts',
+                                                                                   'E_cfg5_wide_norefine_1e5'):
         assert not (path & capi.PATH_MESH_FANS), (path, route)          # (no coarse level / tables beyond the LDS: no fans)
     else:
         assert path & capi.PATH_MESH_FANS, (path, route)
@@ -481,6 +482,31 @@ def test_cfg5_toroidal_mesh_crystal_41x41_1e9_photons(tag):
     n_gpu, i_gpu = _trace(flat, seeds[:4])
     n_cpu, i_cpu = helpers.oracle_counts(flat, seeds[:4], 1, threads=4)
     assert np.array_equal(n_gpu, n_cpu) and np.array_equal(i_gpu[:flat.image_bins], i_cpu[:flat.image_bins])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag', ['flat', 'interp', 'norefine'])
+def test_cfg5_geometry_with_many_reflections_equals_the_oracle(tag):
+    """The cfg5 geometry with a rocking curve wide enough to reflect (goldens E_cfg5_wide_*: 2.6 - 2.8e3 detector hits per 2e5 rays,
+    where cfg5's own 48 urad curve gives 0 - 7): 64 runs x 1e6 rays against the oracle -- the three counters and all 15 000
+    pixels -- and the reference's golden on its own two runs.  (What tests/soak_mesh.py does by hand.)"""
+    name = 'E_cfg5_wide_%s_1e5' % tag
+    config, elements, flat = helpers.build(_full_size(name, 64, {'intensity': 1000000}))
+    seeds = xrt.run_seeds(config['general']['random_seed'], 64)
+    capi.lib().xrt_last_path(1)
+    n_gpu, i_gpu = _trace(flat, seeds)
+    assert capi.lib().xrt_last_path(1) & capi.PATH_MESH_SPLIT
+    n_cpu, i_cpu = helpers.oracle_counts(flat, seeds, 1, threads=16)
+    assert int(n_gpu[0]) == 64 * 10 ** 6 and int(n_gpu[2]) > 500000
+    assert np.array_equal(n_gpu, n_cpu)
+    assert flat.image_bins == 15000 and np.array_equal(i_gpu[:flat.image_bins], i_cpu[:flat.image_bins])
+    cfg, gold = helpers.load_golden(name)
+    config2, elements2, flat2 = helpers.build(cfg)
+    n2, i2 = _trace(flat2, xrt.run_seeds(config2['general']['random_seed'], 2))
+    assert [int(v) for v in n2] == [int(gold['num_out/' + nm]) for nm in flat2.names]
+    for nm in flat2.names[1:]:
+        off, nx, ny = flat2.image_slices[nm]
+        assert np.array_equal(i2[off:off + nx * ny].reshape(nx, ny), gold['image/' + nm]), nm
 
 
 @pytest.mark.gpu

@@ -3169,6 +3169,7 @@ static size_t mesh_bytes(const xrt_mesh_t* m)
     b += al256((n_first + 1) * 96);                                   // point-source form of the first pass
     if (Cn > 0) b += al256(F * 128);                                  // plane form of every face (second pass)
     b += al256(P * 16) + al256(F * 8);                                // 16-bit tables of the LDS form
+    b += al256(P * 48);                                               // the fans (KMesh.lds_star)
     b += al256(128 * 128 * 16);                                       // direction grid of the point-source form
     return b;
 }
