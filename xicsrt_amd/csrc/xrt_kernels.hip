@@ -1150,6 +1150,11 @@ struct KArgs {
     uint32_t* slow_cnt;                 // [n_runs][cand_cap / 64]   xrt_mesh_slow_compact_kernel closes the gaps per unit (slow_q2, unit_slow),
     uint32_t* slow_q2;                  // [n_runs][cand_cap]         and the list walk reads that (its slow_q = this slow_q2)
     uint32_t* unit_slow;                // [n_runs][n_seg * n_sub]
+    // The work of the launches with tables in LDS (one 1024-thread workgroup per CU): the blocks of 1024 records that hold
+    // rays, as a list (unit, block, records of the unit) made by xrt_mesh_items_kernel -- a workgroup reads its next item
+    // instead of looking through the units' counts for it, a round trip to memory per block looked at.
+    const uint4* items;                 // [n_runs * n_seg * n_sub * blocks per unit]
+    const uint32_t* n_items;            // [1]
     uint32_t  slow_pass;
     // What a parked ray's record holds between the launches.  A mesh that is not interpolated (split_interp == 0): its
     // (local-frame) origin and direction [, wavelength] as the first phase left them, and in cand_aux the face its
@@ -2532,7 +2537,7 @@ void xrt_mesh_rest_kernel(const KScene* __restrict__ scene_g, const KArgs args, 
 // normal's first component) are left for xrt_mesh_ct_kernel, which interpolates, checks the bounds and counts.
 template <bool DEFER>
 __global__ __launch_bounds__(XRT_MESH_LDS_THREADS)
-void xrt_mesh_rest_lds_kernel(const KScene* __restrict__ scene_g, const KArgs args, int be, uint32_t blocks_per_unit, uint32_t n_units)
+void xrt_mesh_rest_lds_kernel(const KScene* __restrict__ scene_g, const KArgs args, int be)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const KScene* scl = scene_fresh(scene_g);
@@ -2566,12 +2571,11 @@ void xrt_mesh_rest_lds_kernel(const KScene* __restrict__ scene_g, const KArgs ar
     const bool q_has_wl = !(SRC.wavelength_dist == XRT_WL_CONST && !SRC.has_velocity);
     const int q_ncomp = (args.split_interp ? 9 : 6) + (q_has_wl ? 1 : 0);
     const uint32_t upr = (uint32_t)args.n_seg * (uint32_t)args.n_sub;
-    const uint64_t items = (uint64_t)n_units * blocks_per_unit;             // (unit, block of 1024 rays)
-    for (uint64_t it = blockIdx.x; it < items; it += gridDim.x) {
-        const uint32_t unit = (uint32_t)(it / blocks_per_unit), blk = (uint32_t)(it - (uint64_t)unit * blocks_per_unit);
-        // (slow_pass: only the rays xrt_mesh_star_lds_kernel listed, see KArgs.slow_q)
-        const uint32_t n_unit = args.slow_pass ? uni32(args.unit_slow[unit]) : uni32(args.unit_flag[unit]) - 1u;
-        if (1024u * blk >= n_unit) continue;
+    // (unit, block of 1024 rays) from the list of the blocks that hold rays; slow_pass: the rays xrt_mesh_star_lds_kernel listed
+    const uint32_t n_it = uni32(*args.n_items);
+    for (uint32_t ii = blockIdx.x; ii < n_it; ii += gridDim.x) {
+        const uint4 item = args.items[ii];
+        const uint32_t unit = uni32(item.x), blk = uni32(item.y), n_unit = uni32(item.z);
         const uint32_t run = unit / upr, uidx = unit - run * upr;
         const uint32_t seg = uidx / (uint32_t)args.n_sub, sub = uidx - seg * (uint32_t)args.n_sub;
         const int64_t seg_lo = (int64_t)seg * args.seg_len;
@@ -2626,7 +2630,7 @@ void xrt_mesh_rest_lds_kernel(const KScene* __restrict__ scene_g, const KArgs ar
 // points (also the vertex table), the fans, the faces of the first pass.
 template <bool DEFER>
 __global__ __launch_bounds__(XRT_MESH_LDS_THREADS)
-void xrt_mesh_star_lds_kernel(const KScene* __restrict__ scene_g, const KArgs args, int be, uint32_t blocks_per_unit, uint32_t n_units, uint32_t units_lds)
+void xrt_mesh_star_lds_kernel(const KScene* __restrict__ scene_g, const KArgs args, int be)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const KScene* scl = scene_fresh(scene_g);
@@ -2638,9 +2642,6 @@ void xrt_mesh_star_lds_kernel(const KScene* __restrict__ scene_g, const KArgs ar
     d4v* l_cells = reinterpret_cast<d4v*>(lds_raw);
     uint32_t* l_star = reinterpret_cast<uint32_t*>(l_cells + nc);              // [np][12] words
     double* l_first = reinterpret_cast<double*>(l_star + 12u * np);
-    // (the units' ray counts, when they fit behind the tables: finding a wave's next block then costs LDS reads instead of a
-    //  round trip to memory per block looked at)
-    uint32_t* l_units = reinterpret_cast<uint32_t*>(l_first + 10u * n1);
     {
         const XRT_G1 d4v* g = M.cells;
         for (uint32_t i = (uint32_t)tid; i < nc; i += XRT_MESH_LDS_THREADS) l_cells[i] = g[i];
@@ -2648,7 +2649,6 @@ void xrt_mesh_star_lds_kernel(const KScene* __restrict__ scene_g, const KArgs ar
         for (uint32_t i = (uint32_t)tid; i < 12u * np; i += XRT_MESH_LDS_THREADS) l_star[i] = gs[i];
         const XRT_G1 double* g1 = (const XRT_G1 double*)(uint64_t)M.first_rec;
         for (uint32_t i = (uint32_t)tid; i < 10u * n1; i += XRT_MESH_LDS_THREADS) l_first[i] = g1[i];
-        for (uint32_t i = (uint32_t)tid; i < units_lds; i += XRT_MESH_LDS_THREADS) l_units[i] = args.unit_flag[i];
     }
     __syncthreads();
     MeshStarLds L;
@@ -2659,16 +2659,15 @@ void xrt_mesh_star_lds_kernel(const KScene* __restrict__ scene_g, const KArgs ar
     const bool q_has_wl = !(SRC.wavelength_dist == XRT_WL_CONST && !SRC.has_velocity);
     const int q_ncomp = (args.split_interp ? 9 : 6) + (q_has_wl ? 1 : 0);
     const uint32_t upr = (uint32_t)args.n_seg * (uint32_t)args.n_sub;
-    const uint64_t items = (uint64_t)n_units * blocks_per_unit;             // (unit, block of 1024 rays)
     // Two blocks per round: a block's records are read once, ~2 us after they are asked for, and sixteen waves per CU do not
     // cover that; with the records of two blocks asked for up front the second block's arrive while the first is worked on.
     struct Block { uint32_t unit, k, n_unit; size_t crun; int64_t ray_lo; double* c; bool have; };
-    auto locate = [&](uint64_t it, Block& B) __attribute__((always_inline)) -> uint64_t {
-        // the next item at or behind `it` with rays in it (none: returns `items`)
-        for (; it < items; it += gridDim.x) {
-            const uint32_t unit = (uint32_t)(it / blocks_per_unit), blk = (uint32_t)(it - (uint64_t)unit * blocks_per_unit);
-            const uint32_t n_unit = uni32(unit < units_lds ? l_units[unit] : args.unit_flag[unit]) - 1u;
-            if (1024u * blk >= n_unit) continue;
+    const uint32_t items = uni32(*args.n_items);
+    auto locate = [&](uint32_t it, Block& B) __attribute__((always_inline)) -> uint32_t {
+        // item `it` of the list of the blocks that hold rays (beyond its end: returns `items`)
+        if (it < items) {
+            const uint4 item = args.items[it];
+            const uint32_t unit = uni32(item.x), blk = uni32(item.y), n_unit = uni32(item.z);
             const uint32_t run = unit / upr, uidx = unit - run * upr;
             const uint32_t seg = uidx / (uint32_t)args.n_sub, sub = uidx - seg * (uint32_t)args.n_sub;
             const int64_t seg_lo = (int64_t)seg * args.seg_len;
@@ -2729,12 +2728,12 @@ void xrt_mesh_star_lds_kernel(const KScene* __restrict__ scene_g, const KArgs ar
             }
         }
     };
-    uint64_t it = blockIdx.x;
+    uint32_t it = blockIdx.x;
     for (;;) {
         Block A, B;
-        const uint64_t ia = locate(it, A);
+        const uint32_t ia = locate(it, A);
         if (ia >= items) break;
-        const uint64_t ib = locate(ia + gridDim.x, B);
+        const uint32_t ib = locate(ia + gridDim.x, B);
         // both blocks' records: asked for here, used below
         double ra[6], rb[6];
         int fa = 0, fb = 0;
@@ -2754,6 +2753,36 @@ void xrt_mesh_star_lds_kernel(const KScene* __restrict__ scene_g, const KArgs ar
         if (ib < items) work(B, rb, fb);
         it = ib + gridDim.x;
     }
+}
+
+// The blocks of 1024 records that hold rays (KArgs.items), units in order: counts[u] - minus records in unit u.
+__global__ __launch_bounds__(1024)
+void xrt_mesh_items_kernel(const uint32_t* counts, uint32_t minus, uint32_t n_units, uint4* items, uint32_t* n_items)
+{
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t running;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) running = 0u;
+    __syncthreads();
+    for (uint32_t u0 = 0; u0 < n_units; u0 += 1024u) {
+        const uint32_t u = u0 + tid;
+        const uint32_t n = u < n_units ? counts[u] - minus : 0u;
+        const uint32_t nb = (n + 1023u) >> 10;
+        part[tid] = nb;
+        __syncthreads();
+        for (uint32_t off = 1u; off < 1024u; off <<= 1) {
+            const uint32_t v = tid >= off ? part[tid - off] : 0u;
+            __syncthreads();
+            part[tid] += v;
+            __syncthreads();
+        }
+        const uint32_t at = running + part[tid] - nb;
+        for (uint32_t b = 0; b < nb; b++) { uint4 it; it.x = u; it.y = b; it.z = n; it.w = 0u; items[at + b] = it; }
+        __syncthreads();
+        if (tid == 1023u) running += part[1023];
+        __syncthreads();
+    }
+    if (tid == 0) *n_items = running;
 }
 
 // The fan launch's lists (per 64 records of a unit) without their gaps: per unit one dense list for the launch that walks the
@@ -2854,7 +2883,7 @@ void xrt_mesh_ct_kernel(const KScene* __restrict__ scene_g, const KArgs args, in
 // mesh whose table fits (41 x 41 points: 161 376 of the 163 840 bytes): 24 of a ray's ~40 gathers then cost an LDS read
 // instead of an L1 tag lookup per lane.  One 1024-thread workgroup per CU, blocks of 1024 parked rays round robin.
 __global__ __launch_bounds__(XRT_MESH_LDS_THREADS)
-void xrt_mesh_ct_lds_kernel(const KScene* __restrict__ scene_g, const KArgs args, int be, uint32_t blocks_per_unit, uint32_t n_units)
+void xrt_mesh_ct_lds_kernel(const KScene* __restrict__ scene_g, const KArgs args, int be)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const KScene* scl = scene_fresh(scene_g);
@@ -2874,11 +2903,10 @@ void xrt_mesh_ct_lds_kernel(const KScene* __restrict__ scene_g, const KArgs args
     const bool q_has_wl = !(SRC.wavelength_dist == XRT_WL_CONST && !SRC.has_velocity);
     const int q_ncomp = (args.split_interp ? 9 : 6) + (q_has_wl ? 1 : 0);
     const uint32_t upr = (uint32_t)args.n_seg * (uint32_t)args.n_sub;
-    const uint64_t items = (uint64_t)n_units * blocks_per_unit;
-    for (uint64_t it = blockIdx.x; it < items; it += gridDim.x) {
-        const uint32_t unit = (uint32_t)(it / blocks_per_unit), blk = (uint32_t)(it - (uint64_t)unit * blocks_per_unit);
-        const uint32_t n_unit = uni32(args.unit_flag[unit]) - 1u;
-        if (1024u * blk >= n_unit) continue;
+    const uint32_t n_it = uni32(*args.n_items);
+    for (uint32_t ii = blockIdx.x; ii < n_it; ii += gridDim.x) {
+        const uint4 item = args.items[ii];
+        const uint32_t unit = uni32(item.x), blk = uni32(item.y), n_unit = uni32(item.z);
         const uint32_t run = unit / upr, uidx = unit - run * upr;
         const uint32_t seg = uidx / (uint32_t)args.n_sub, sub = uidx - seg * (uint32_t)args.n_sub;
         const int64_t seg_lo = (int64_t)seg * args.seg_len;
@@ -3428,6 +3456,21 @@ static size_t mesh_split_off_slow_q(const xrt_scene_t* sc, int n_runs, const Seg
 static size_t mesh_split_off_slow_cnt(const xrt_scene_t* sc, int n_runs, const SegPlan& p) { return mesh_split_off_slow_q(sc, n_runs, p) + al256((size_t)n_runs * cand_capacity(sc) * 4); }
 static size_t mesh_split_off_slow_q2(const xrt_scene_t* sc, int n_runs, const SegPlan& p) { return mesh_split_off_slow_cnt(sc, n_runs, p) + al256((size_t)n_runs * (cand_capacity(sc) / 64) * 4); }
 static size_t mesh_split_off_unit_slow(const xrt_scene_t* sc, int n_runs, const SegPlan& p) { return mesh_split_off_slow_q2(sc, n_runs, p) + al256((size_t)n_runs * cand_capacity(sc) * 4); }
+// (behind those: the list of the blocks of 1024 records that hold rays, KArgs.items, twice -- all parked rays, and the rays
+//  left to the list walk -- 16 bytes per block, and the lists' lengths)
+static size_t mesh_split_items_max(const xrt_scene_t* sc, int n_runs, const SegPlan& p)
+{
+    const size_t bpu4 = ((size_t)(p.sub_len / XRT_TILE) + 3) / 4;
+    return (size_t)n_runs * (size_t)p.n_seg * (size_t)p.n_sub * bpu4;
+}
+static size_t mesh_split_off_items(const xrt_scene_t* sc, int n_runs, const SegPlan& p)
+{
+    return mesh_split_off_unit_slow(sc, n_runs, p) + al256(sizeof(uint32_t) * (size_t)n_runs * (size_t)p.n_seg * (size_t)p.n_sub);
+}
+static size_t mesh_split_end(const xrt_scene_t* sc, int n_runs, const SegPlan& p)
+{
+    return mesh_split_off_items(sc, n_runs, p) + 2 * al256(16 * mesh_split_items_max(sc, n_runs, p)) + 256;
+}
 static size_t cand_bytes(const xrt_scene_t* sc, int n_runs, size_t budget)
 {
     const SegPlan p = plan_segments(sc, n_runs);
@@ -3436,7 +3479,7 @@ static size_t cand_bytes(const xrt_scene_t* sc, int n_runs, size_t budget)
         // split phases: 10 doubles (+ the normal) and the face per ray, the rays left alive per 64 and per unit.  (A call whose
         // runs would take more than the budget goes through them in batches, mesh_batch_runs; what is left over the budget
         // here is a single run of > 6e8 rays.)
-        const size_t b = mesh_split_off_unit_slow(sc, n_runs, p) + al256(sizeof(uint32_t) * (size_t)n_runs * (size_t)p.n_seg * (size_t)p.n_sub) + 256;
+        const size_t b = mesh_split_end(sc, n_runs, p) + 256;
         return b <= budget ? b : 0;
     }
     if (p.n_seg * p.n_sub <= 1) return 0;
@@ -4888,35 +4931,47 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
             const unsigned long long items = (unsigned long long)n_runs * (unsigned long long)(S * M) * bpu4;
             const unsigned grid = (unsigned)(items < (unsigned long long)c_cus3 ? items : (unsigned long long)c_cus3);
             const uint32_t n_units = (uint32_t)(n_runs * S * M);
+            // the work of the launches with tables in LDS: the blocks of 1024 records that hold rays (KArgs.items)
+            uint4* d_items = nullptr;
+            uint32_t* d_nitems = nullptr;
+            if (lds_m > 0 || lds_ct > 0) {
+                char* cb = ws + ws_base_bytes(sc, n_runs);
+                d_items = reinterpret_cast<uint4*>(cb + mesh_split_off_items(sc, n_runs, plan));
+                d_nitems = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(d_items) + 2 * al256(16 * mesh_split_items_max(sc, n_runs, plan)));
+                hipLaunchKernelGGL(xrt_mesh_items_kernel, dim3(1), dim3(1024), 0, stream, am.unit_flag, 1u, n_units, d_items, d_nitems);
+                HIP_TRY(hipGetLastError());
+                am.items = d_items; am.n_items = d_nitems;
+            }
             // a mesh with fans: what one face of the nearest point's fan settles first, the launch below for the rays left over
             const int lds_st = ks.opt[be].mesh_star_lds_bytes;
             if (lds_m > 0 && lds_st > 0) {
-                // (the units' counts behind the tables, as many as fit)
-                uint32_t units_lds = n_units;
-                if ((size_t)lds_st + 4 * (size_t)units_lds > 160u * 1024u) units_lds = (uint32_t)((160u * 1024u - (size_t)lds_st) / 4);
-                const size_t lds_su = (size_t)lds_st + 4 * (size_t)units_lds;
                 if (ct) {
-                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(xrt_mesh_star_lds_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_su));
-                    hipLaunchKernelGGL((xrt_mesh_star_lds_kernel<true>), dim3(grid), dim3(XRT_MESH_LDS_THREADS), lds_su, stream, device_scene(ws), am, be, bpu4, n_units, units_lds);
+                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(xrt_mesh_star_lds_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_st));
+                    hipLaunchKernelGGL((xrt_mesh_star_lds_kernel<true>), dim3(grid), dim3(XRT_MESH_LDS_THREADS), (size_t)lds_st, stream, device_scene(ws), am, be);
                 } else {
-                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(xrt_mesh_star_lds_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_su));
-                    hipLaunchKernelGGL((xrt_mesh_star_lds_kernel<false>), dim3(grid), dim3(XRT_MESH_LDS_THREADS), lds_su, stream, device_scene(ws), am, be, bpu4, n_units, units_lds);
+                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(xrt_mesh_star_lds_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_st));
+                    hipLaunchKernelGGL((xrt_mesh_star_lds_kernel<false>), dim3(grid), dim3(XRT_MESH_LDS_THREADS), (size_t)lds_st, stream, device_scene(ws), am, be);
                 }
                 HIP_TRY(hipGetLastError());
                 hipLaunchKernelGGL(xrt_mesh_slow_compact_kernel, dim3(n_units < 2048u ? n_units : 2048u), dim3(256), 0, stream, device_scene(ws), am, n_units);
                 HIP_TRY(hipGetLastError());
                 am.slow_pass = 1;
                 am.slow_q = am.slow_q2;
+                // (the list walk's own items: the blocks of the units' lists of rays left over)
+                uint4* d_items2 = reinterpret_cast<uint4*>(reinterpret_cast<char*>(d_items) + al256(16 * mesh_split_items_max(sc, n_runs, plan)));
+                hipLaunchKernelGGL(xrt_mesh_items_kernel, dim3(1), dim3(1024), 0, stream, am.unit_slow, 0u, n_units, d_items2, d_nitems + 1);
+                HIP_TRY(hipGetLastError());
+                am.items = d_items2; am.n_items = d_nitems + 1;
                 g_paths |= XRT_PATH_MESH_FANS;
             }
             // up to the hit face (an interpolated mesh: the rest is the next launch's)
             if (lds_m > 0) {
                 if (ct) {
                     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(xrt_mesh_rest_lds_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_m));
-                    hipLaunchKernelGGL((xrt_mesh_rest_lds_kernel<true>), dim3(grid), dim3(XRT_MESH_LDS_THREADS), (size_t)lds_m, stream, device_scene(ws), am, be, bpu4, n_units);
+                    hipLaunchKernelGGL((xrt_mesh_rest_lds_kernel<true>), dim3(grid), dim3(XRT_MESH_LDS_THREADS), (size_t)lds_m, stream, device_scene(ws), am, be);
                 } else {
                     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(xrt_mesh_rest_lds_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_m));
-                    hipLaunchKernelGGL((xrt_mesh_rest_lds_kernel<false>), dim3(grid), dim3(XRT_MESH_LDS_THREADS), (size_t)lds_m, stream, device_scene(ws), am, be, bpu4, n_units);
+                    hipLaunchKernelGGL((xrt_mesh_rest_lds_kernel<false>), dim3(grid), dim3(XRT_MESH_LDS_THREADS), (size_t)lds_m, stream, device_scene(ws), am, be);
                 }
             } else if (ct)
                 hipLaunchKernelGGL((xrt_mesh_rest_kernel<true>), dim3((unsigned)blocks), dim3(XRT_TILE), 0, stream, device_scene(ws), am, be, bpu);
@@ -4924,11 +4979,12 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
                 hipLaunchKernelGGL((xrt_mesh_rest_kernel<false>), dim3((unsigned)blocks), dim3(XRT_TILE), 0, stream, device_scene(ws), am, be, bpu);
             HIP_TRY(hipGetLastError());
             am.slow_pass = 0;
+            am.items = d_items; am.n_items = d_nitems;
             // interpolation, bounds, counts
             if (ct) {
                 if (lds_ct > 0) {
                     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(xrt_mesh_ct_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_ct));
-                    hipLaunchKernelGGL(xrt_mesh_ct_lds_kernel, dim3(grid), dim3(XRT_MESH_LDS_THREADS), (size_t)lds_ct, stream, device_scene(ws), am, be, bpu4, n_units);
+                    hipLaunchKernelGGL(xrt_mesh_ct_lds_kernel, dim3(grid), dim3(XRT_MESH_LDS_THREADS), (size_t)lds_ct, stream, device_scene(ws), am, be);
                 } else
                     hipLaunchKernelGGL(xrt_mesh_ct_kernel, dim3((unsigned)blocks), dim3(XRT_TILE), 0, stream, device_scene(ws), am, be, bpu);
             }
