@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define XRT_ABI_VERSION 18
+#define XRT_ABI_VERSION 19
 
 #define XRT_MAX_OPTICS     64
 #define XRT_MAX_APERTURES  32
@@ -437,6 +437,10 @@ int xrt_legacy_shuffle_head(xrt_rng_state_t* state, int64_t n, int64_t m, int64_
  * such that state_word[n + J] = XOR over {j : g_j = 1} of state_word[n + j].
  * Replaces nothing in the reference (np.random walks its stream sequentially). */
 int xrt_mt_jump_poly(uint64_t J, uint32_t* out624);
+/* ... n of them at once (out: n x 624 words), the way a plan's jump jobs get theirs: the exponents of a plan come in
+ * arithmetic families (segment s of array k, chunk head c), and a polynomial is its neighbour's times t^step -- one
+ * carry-less product and reduction instead of a square-and-multiply from scratch.  Same results as xrt_mt_jump_poly. */
+int xrt_mt_jump_polys(const uint64_t* J, int32_t n, uint32_t* out);
 
 /* Name and average duration (ms) bookkeeping of the propagation kernel for the
  * benchmark: brackets the kernel launches of the next xrt_trace calls with HIP

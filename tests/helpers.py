@@ -142,22 +142,34 @@ RTOL_CASE = {'I2_ToroidalCrystal_trace': 1e-9}
 # 7e-13 there; the device (its own square roots, divisions and last-ulp transcendental differences, amplified by the
 # ill-conditioned point) to 1.7e-9 and 1.3e-8.  Masks, counters and pixels are equal; the task's bound is 1e-6.
 RTOL_CASE_DEVICE = {'Y_fuzz_9011073_trace': 1e-7, 'Y_fuzz_9015074_trace': 1e-7, 'Y_fuzz_14039276_trace': 1e-7}
+# ... and how many rays of the scene may need it (every other ray is held to the tight tolerance): measured on the device,
+# three of the 40 000 rays of Y_fuzz_9011073 (30456, 31178, 38131) and of Y_fuzz_14039276 (12085, 23654, 36193) -- rays on
+# or next to a double root of the torus quartic / grazing the next plane
+OUTLIER_RAYS = {'Y_fuzz_9011073_trace': 4, 'Y_fuzz_9015074_trace': 4, 'Y_fuzz_14039276_trace': 4}
 
 
 def rtol_for(name, device=False):
-    tol = RTOL_CASE.get(name, RTOL_DEFAULT)
-    return max(tol, RTOL_CASE_DEVICE.get(name, 0.0)) if device else tol
+    """The tolerance every ray of the case is held to.  (The device's looser bound for the Y_fuzz cases applies to ONE ray of
+    the scene only: see outlier_rtol_for.)"""
+    return RTOL_CASE.get(name, RTOL_DEFAULT)
 
 
-def assert_history_matches_golden(flat, rays, mask, gold, rtol=1e-12):
+def outlier_rtol_for(name, device=False):
+    """The bound for the single ill-conditioned ray of a Y_fuzz case on the device (None: the case has no such ray)."""
+    return RTOL_CASE_DEVICE.get(name) if device else None
+
+
+def assert_history_matches_golden(flat, rays, mask, gold, rtol=1e-12, outlier_rtol=None, max_outliers=1):
     """
     Compare a device/oracle history snapshot with a golden 'trace' fixture:
     masks bit-exact for every ray at every element; origin, direction and
     wavelength of rays alive after the element within `rtol` (relative to the
     vector's magnitude); rays that died at an element carry the point they
-    died at, NaN pattern included.
+    died at, NaN pattern included.  `outlier_rtol`: `max_outliers` rays of the
+    scene (the same rays at every element) may be off by up to that instead.
     """
     hist = xrt._history_from_device(flat.names, rays, mask, flat.optic_objs)
+    outliers = set()
     for name in flat.names:
         gm = gold['mask/' + name]
         assert np.array_equal(hist[name]['mask'], gm), 'mask mismatch at %s' % name
@@ -166,9 +178,16 @@ def assert_history_matches_golden(flat, rays, mask, gold, rtol=1e-12):
             h = hist[name][key]
             assert np.array_equal(np.isnan(h), np.isnan(g)), 'NaN pattern of %s at %s' % (key, name)
             ok = ~np.isnan(g)
-            scale = np.max(np.abs(g[ok])) if ok.any() else 1.0
-            err = np.max(np.abs(h[ok] - g[ok])) if ok.any() else 0.0
-            assert err <= rtol * max(scale, 1e-300), '%s at %s: err %.3e (scale %.3e)' % (key, name, err, scale)
+            scale = max(np.max(np.abs(g[ok])) if ok.any() else 1.0, 1e-300)
+            diff = np.where(ok, np.abs(h - g), 0.0)
+            per_ray = diff.reshape(diff.shape[0], -1).max(axis=1) if diff.size else np.zeros(0)
+            err = per_ray.max() if per_ray.size else 0.0
+            if outlier_rtol is None:
+                assert err <= rtol * scale, '%s at %s: err %.3e (scale %.3e)' % (key, name, err, scale)
+            else:
+                outliers |= set(np.flatnonzero(per_ray > rtol * scale).tolist())
+                assert err <= outlier_rtol * scale, '%s at %s: err %.3e (scale %.3e)' % (key, name, err, scale)
+    assert len(outliers) <= max_outliers, 'more than %d rays beyond %.1e: %s' % (max_outliers, rtol, sorted(outliers))
 
 
 class OracleDeviceTrace:

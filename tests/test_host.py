@@ -336,6 +336,28 @@ def test_jump_polynomials_satisfy_the_generator_recurrence():
             assert acc == s[n + J], (J, n)
 
 
+def test_jump_polynomials_of_a_plan_come_out_as_from_scratch():
+    """A plan's jump polynomials are made in families -- t^(J + step) = t^J . t^step mod phi, one carry-less product -- and must
+    be the polynomials square-and-multiply gives for every exponent: the offsets of a segmented plan (arrays x segments, chunk
+    heads), duplicates and stragglers included."""
+    import time
+    L = capi.lib()
+    N, Lseg, CH, ahead = 10_000_000, 9984, 20480, 512
+    Js = [2 * (k * N + s * Lseg) - ahead for k in (3, 4) for s in range(40)] + [2 * 5 * N + c * CH - ahead for c in range(60)]
+    Js += [Js[5], 7, 123456789, 2 * 5 * N + 61 * CH - ahead + 2]
+    arr = (C.c_uint64 * len(Js))(*Js)
+    out = (C.c_uint32 * (624 * len(Js)))()
+    t0 = time.time()
+    assert L.xrt_mt_jump_polys(arr, len(Js), out) == 0
+    t_family = time.time() - t0
+    got = np.frombuffer(out, dtype=np.uint32).reshape(len(Js), 624)
+    buf = (C.c_uint32 * 624)()
+    for i in list(range(0, len(Js), 7)) + [len(Js) - 4, len(Js) - 3, len(Js) - 2, len(Js) - 1]:
+        assert L.xrt_mt_jump_poly(Js[i], buf) == 0
+        assert np.array_equal(got[i], np.frombuffer(buf, dtype=np.uint32)), (i, Js[i])
+    assert t_family < 30.0
+
+
 def test_weideman_faddeeva_reproduces_the_voigt_tables_of_scipy():
     """The per-bundle Voigt tables are built on the device with Weideman's approximation of Re w(z); with the
     coefficients the host hands over, the table of tools/xicsrt_voigt.py (restated here with scipy.special.wofz)

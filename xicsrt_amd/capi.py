@@ -17,7 +17,7 @@ EXPORTS = (
     'xrt_device_count', 'xrt_workspace_bytes', 'xrt_trace', 'xrt_trace_history',
     'xrt_timing_begin', 'xrt_timing_end', 'xrt_mt_jump_poly', 'xrt_check', 'xrt_make_image', 'xrt_last_path',
     'xrt_optic_intersect', 'xrt_optic_check_bounds', 'xrt_optic_interact', 'xrt_selftest_div3', 'xrt_legacy_shuffle_head',
-    'xrt_status_offset', 'xrt_set_workspace_budget',
+    'xrt_status_offset', 'xrt_set_workspace_budget', 'xrt_mt_jump_polys',
 )
 PATH_FUSED, PATH_STAGED, PATH_STAGE_SPLIT, PATH_JUMP, PATH_SEEK, PATH_SEGMENTED, PATH_GAUSS_PREPARED = 1, 2, 4, 8, 16, 32, 64
 PATH_PLASMA_SCOUT = 128
@@ -68,6 +68,8 @@ def lib():
                                     C.c_void_p, C.c_size_t, C.c_void_p]
     L.xrt_mt_jump_poly.restype = C.c_int
     L.xrt_mt_jump_poly.argtypes = [C.c_uint64, P(C.c_uint32)]
+    L.xrt_mt_jump_polys.restype = C.c_int
+    L.xrt_mt_jump_polys.argtypes = [P(C.c_uint64), C.c_int32, P(C.c_uint32)]
     L.xrt_check.restype = C.c_int
     L.xrt_check.argtypes = [C.c_void_p, C.c_void_p]
     L.xrt_make_image.restype = C.c_int

@@ -4595,10 +4595,11 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
             const int nb = (n_runs - base_run) < slots ? (n_runs - base_run) : slots;
             ps.run_base = base_run; ps.n_runs = nb;
             const bool voigt = sc->source.plasma && sc->source.plasma->voigt_gamma > 0.0;
-            const size_t scout_lds = voigt ? 4 * 2 * XRT_VOIGT_GRID * sizeof(double) : 0;
+            // (bundles with a Voigt table of their own: one wave -- one run -- per workgroup, its table in LDS; see the kernel)
+            const size_t scout_lds = voigt ? 2 * XRT_VOIGT_GRID * sizeof(double) : 0;
             if (voigt) {
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(xrt_plasma_scout_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scout_lds));
-                hipLaunchKernelGGL((xrt_plasma_scout_kernel<true, true>), dim3((nb + 3) / 4), dim3(256), scout_lds, stream, device_scene(ws), streams, ps);
+                hipLaunchKernelGGL((xrt_plasma_scout_kernel<true, true>), dim3(nb), dim3(64), scout_lds, stream, device_scene(ws), streams, ps);
             } else if (sc->source.plasma)
                 hipLaunchKernelGGL((xrt_plasma_scout_kernel<false, true>), dim3((nb + 3) / 4), dim3(256), 0, stream, device_scene(ws), streams, ps);
             else
@@ -5517,6 +5518,14 @@ extern "C" int xrt_legacy_shuffle_head(xrt_rng_state_t* state, int64_t n, int64_
     }
     for (int64_t q = 0; q < m; q++) out[q] = (int64_t)x[(size_t)q];
     state->pos = pos;
+    return 0;
+}
+
+// diagnostic: n such polynomials at once, as a plan's jump jobs get them (families of exponents through products); host only
+extern "C" int xrt_mt_jump_polys(const uint64_t* J, int32_t n, uint32_t* out)
+{
+    if (!J || !out || n < 0) return fail(-1, "%s", "NULL argument");
+    if (!mtjump::jump_polys(J, n, out)) return fail(-5, "%s", "MT19937 characteristic polynomial could not be derived");
     return 0;
 }
 

@@ -20,7 +20,7 @@ import ctypes as C
 
 import numpy as np
 
-XRT_ABI_VERSION = 18
+XRT_ABI_VERSION = 19
 XRT_WS_STATUS_BYTE = 64        # include/xicsrt_hip.h: the uint32 xrt_check reads (checked against xrt_status_offset())
 XRT_MAX_BUNDLE_FILTERS = 16
 XRT_MAX_OPTICS = 64
