@@ -3790,10 +3790,87 @@ static size_t plan_queue(const KScene& ks, int n_src_heads, bool ext, bool hist,
 }
 
 // device copy of every mesh's tables behind the staged region; fills KOptic.mesh
+// ---- the packed tables of a mesh, kept between calls -------------------------------------------------------------------
+// Everything upload_meshes derives from a mesh -- face records, plane forms, the point-source form and the direction grid,
+// the bucket grid, the 16-bit tables and the fans, the Clough-Tocher records -- depends on the mesh, on the optic's frame and
+// on the source point only: milliseconds of host work per call (3.5 ms for an 81 x 81 mesh), behind a stream synchronisation,
+// for every batch of runs and every second pass.  The region's bytes are therefore kept (in pinned host memory, keyed by a
+// 128-bit fingerprint of all inputs and switches); a later call copies them, asynchronously on its stream, to wherever its
+// layout puts the region, with the header's pointers moved along.
+struct MeshFp { uint64_t a, b; };
+static void fp_mix(MeshFp& f, const void* data, size_t bytes)
+{
+    if (!data || !bytes) { f.a = (f.a ^ 0x51ull) * 0x9E3779B97F4A7C15ull; f.b += 0x7full; return; }
+    const unsigned char* c = reinterpret_cast<const unsigned char*>(data);
+    uint64_t a = f.a, b = f.b ^ (uint64_t)bytes;
+    size_t i = 0;
+    for (; i + 8 <= bytes; i += 8) {
+        uint64_t x;
+        memcpy(&x, c + i, 8);
+        a = (a ^ x) * 0x9E3779B97F4A7C15ull; a ^= a >> 29;
+        b = (b + x) * 0xC2B2AE3D27D4EB4Full; b ^= b >> 31;
+    }
+    if (i < bytes) {
+        uint64_t x = 0;
+        memcpy(&x, c + i, bytes - i);
+        a = (a ^ x) * 0x9E3779B97F4A7C15ull; a ^= a >> 29;
+        b = (b + x) * 0xC2B2AE3D27D4EB4Full; b ^= b >> 31;
+    }
+    f.a = a; f.b = b;
+}
+static MeshFp mesh_fingerprint(const xrt_scene_t* sc, int e)
+{
+    const xrt_mesh_t* m = sc->optics[e].mesh;
+    const size_t P = (size_t)m->n_points, F = (size_t)m->n_faces, Cn = (size_t)m->n_coarse_faces, T = (size_t)m->n_simplices;
+    MeshFp f = {0x243F6A8885A308D3ull, 0x13198A2E03707344ull};
+    const int32_t head[8] = {m->n_points, m->n_faces, m->n_coarse_faces, m->interpolate, m->n_simplices, e, sc->source.kind, sc->source.spatial_dist};
+    fp_mix(f, head, sizeof(head));
+    uint32_t sw = 0;
+    const char* names[] = {"XICSRT_NO_DIR_GRID", "XICSRT_NO_MESH_LDS", "XICSRT_NO_FACE_GRID", "XICSRT_NO_POINT_FORM", "XICSRT_NO_MESH_FANS"};
+    for (int i = 0; i < 5; i++) if (env_on(names[i])) sw |= 1u << i;
+    fp_mix(f, &sw, sizeof(sw));
+    fp_mix(f, sc->optics[e].origin, 24); fp_mix(f, sc->optics[e].orientation, 72);
+    fp_mix(f, sc->source.origin, 24); fp_mix(f, sc->source.size, 24);
+    fp_mix(f, m->points, P * 24);
+    fp_mix(f, m->p0, F * 24); fp_mix(f, m->p1, F * 24); fp_mix(f, m->p2, F * 24);
+    fp_mix(f, m->edge1, F * 24); fp_mix(f, m->edge2, F * 24);
+    fp_mix(f, m->faces_normal, F * 24); fp_mix(f, m->faces_area, F * 8);
+    fp_mix(f, m->p_faces_idx, P * 32); fp_mix(f, m->p_faces_mask, P * 8);
+    fp_mix(f, m->c_p0, Cn * 24); fp_mix(f, m->c_edge1, Cn * 24); fp_mix(f, m->c_edge2, Cn * 24);
+    if (m->interpolate) {
+        fp_mix(f, m->ct_simplices, T * 12); fp_mix(f, m->ct_neighbors, T * 12); fp_mix(f, m->ct_transform, T * 48);
+        fp_mix(f, m->ct_points, P * 16); fp_mix(f, m->ct_values, P * 32); fp_mix(f, m->ct_grad, P * 64);
+        fp_mix(f, m->ct_vertex_simplex, P * 4);
+    }
+    return f;
+}
+struct MeshCacheEntry {
+    MeshFp fp;
+    int dev;
+    char* pinned;               // the region's bytes (hipHostMalloc)
+    size_t bytes;
+    uintptr_t base0;            // the device address the header's pointers were made for
+    KMesh k;
+    int32_t lds_bytes, star_lds_bytes, ct_lds_bytes, dir_bytes;
+    uint64_t used;
+};
+static std::mutex g_mesh_mu;
+static std::vector<MeshCacheEntry> g_mesh_cache;
+static uint64_t g_mesh_tick = 0;
+// the header's device pointers, moved by `delta` bytes
+static void kmesh_relocate(KMesh& k, ptrdiff_t delta)
+{
+    auto mv = [&](auto& ptr) { if (ptr) ptr = reinterpret_cast<std::remove_reference_t<decltype(ptr)>>(reinterpret_cast<uintptr_t>(ptr) + (uintptr_t)delta); };
+    mv(k.faces_normal); mv(k.first_rec); mv(k.plane_rec); mv(k.face_rec); mv(k.point_faces);
+    mv(k.ct_srec); mv(k.ct_frec); mv(k.ct_vrec); mv(k.face_simplex); mv(k.ct_vertex_simplex);
+    mv(k.points); mv(k.cells); mv(k.fg_start); mv(k.fg_faces); mv(k.fg_zcell);
+    mv(k.pt_rec); mv(k.dg_cells); mv(k.plane2_rec); mv(k.lds_pf); mv(k.lds_fv); mv(k.lds_star);
+}
+
 static int upload_meshes(const xrt_scene_t* sc, char* ws, int n_runs, KScene* ks, hipStream_t stream)
 {
     char* base = ws + ws_off_staged(sc, n_runs) + staged_bytes(sc, n_runs);
-    bool synced = false;
+    int dev_now = 0;
     for (int e = 0; e < sc->n_optics; e++) {
         ks->opt[e].mesh = nullptr;
         ks->opt[e].mesh_lds_bytes = 0;
@@ -3801,25 +3878,47 @@ static int upload_meshes(const xrt_scene_t* sc, char* ws, int n_runs, KScene* ks
         ks->opt[e].mesh_ct_lds_bytes = 0;
         ks->opt[e].mesh_star_lds_bytes = 0;
         if (sc->optics[e].shape != XRT_SHAPE_MESH) continue;
-        // The packed tables are host temporaries, copied synchronously; an earlier call on `stream` may still be
-        // reading this part of the workspace (with another layout): wait for it first.  (Mesh scenes only; every other
-        // call stays asynchronous.)
-        if (!synced) { HIP_TRY(hipStreamSynchronize(stream)); synced = true; }
         const xrt_mesh_t* m = sc->optics[e].mesh;
+        const size_t region = mesh_bytes(m);
+        HIP_TRY(hipGetDevice(&dev_now));
+        const MeshFp fp = mesh_fingerprint(sc, e);
+        const bool use_cache = !env_on("XICSRT_NO_MESH_CACHE");
+        if (use_cache) {
+            // the tables of an earlier call: the region's bytes from pinned memory, stream-ordered (an earlier call on `stream`
+            // may still be reading this part of the workspace with another layout: the copy queues behind it)
+            std::unique_lock<std::mutex> lock(g_mesh_mu);
+            MeshCacheEntry* hit = nullptr;
+            for (MeshCacheEntry& c : g_mesh_cache)
+                if (c.fp.a == fp.a && c.fp.b == fp.b && c.dev == dev_now && c.bytes == region) hit = &c;
+            if (hit) {
+                hit->used = ++g_mesh_tick;
+                KMesh k = hit->k;
+                kmesh_relocate(k, (ptrdiff_t)((uintptr_t)base - hit->base0));
+                const size_t hdr = al256(sizeof(KMesh));
+                const char* pinned = hit->pinned;
+                const int32_t l0 = hit->lds_bytes, l1 = hit->star_lds_bytes, l2 = hit->ct_lds_bytes, l3 = hit->dir_bytes;
+                lock.unlock();
+                HIP_TRY(hipMemcpyAsync(base + hdr, pinned + hdr, region - hdr, hipMemcpyHostToDevice, stream));
+                HIP_TRY(hipMemcpyAsync(base, &k, sizeof(KMesh), hipMemcpyHostToDevice, stream));     // (pageable: staged by the runtime before it returns)
+                ks->opt[e].mesh = reinterpret_cast<const KMesh*>(base);
+                ks->opt[e].mesh_lds_bytes = l0; ks->opt[e].mesh_star_lds_bytes = l1; ks->opt[e].mesh_ct_lds_bytes = l2; ks->opt[e].mesh_dir_bytes = l3;
+                base += region;
+                continue;
+            }
+        }
         KMesh k;
         memset(&k, 0, sizeof(k));
         k.n_points = m->n_points; k.n_faces = m->n_faces; k.n_coarse_faces = m->n_coarse_faces;
         k.interpolate = m->interpolate; k.n_simplices = m->n_simplices;
         char* p = base + al256(sizeof(KMesh));
-        // synchronous copies throughout: the packed tables are host temporaries
-        hipError_t put_err = hipSuccess;        // (the first failed copy; checked behind the last one)
+        // the region is put together on the host (device addresses in the header, the bytes at the same offsets in `blob`)
+        std::vector<char> blob(region, 0);
+        hipError_t put_err = hipSuccess;
         auto put = [&](const void* src, size_t bytes) -> uintptr_t {
             char* dst = p;
             p += al256(bytes > 0 ? bytes : 8);
-            if (src && bytes) {
-                const hipError_t e = hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
-                if (e != hipSuccess && put_err == hipSuccess) put_err = e;
-            }
+            if ((size_t)(p - base) > region) { put_err = hipErrorOutOfMemory; return (uintptr_t)dst; }
+            if (src && bytes) memcpy(&blob[(size_t)(dst - base)], src, bytes);
             return (uintptr_t)dst;
         };
         const size_t P = (size_t)m->n_points, F = (size_t)m->n_faces, Cn = (size_t)m->n_coarse_faces, T = (size_t)m->n_simplices;
@@ -4399,15 +4498,41 @@ static int upload_meshes(const xrt_scene_t* sc, char* ws, int n_runs, KScene* ks
                 }
             }
         }
-        if (put_err != hipSuccess) return fail(-10, "copy of the mesh tables to the device: %s", hipGetErrorString(put_err));
-        HIP_TRY(hipMemcpy(base, &k, sizeof(KMesh), hipMemcpyHostToDevice));
+        if (put_err != hipSuccess) return fail(-10, "%s", "the mesh tables do not fit their region of the workspace");
+        memcpy(&blob[0], &k, sizeof(KMesh));
         ks->opt[e].mesh = reinterpret_cast<const KMesh*>(base);
         ks->opt[e].mesh_lds_bytes = k.lds_bytes;
         ks->opt[e].mesh_star_lds_bytes = k.star_lds_bytes;
         ks->opt[e].mesh_ct_lds_bytes = (m->interpolate && (size_t)m->n_points * 96 + 64 <= 160u * 1024u && !env_on("XICSRT_NO_MESH_LDS"))
                                            ? (int32_t)((size_t)m->n_points * 96) : 0;
         ks->opt[e].mesh_dir_bytes = (k.dg_n > 0 && !k.dg_big) ? (int32_t)(((size_t)k.n_first + 1) * 96 + (size_t)k.dg_n * k.dg_n * 8) : 0;
-        base += mesh_bytes(m);
+        // into pinned memory (kept for later calls), from there to the device on the stream; without pinned memory: a copy
+        // from the temporary, behind whatever the stream still has to do with this part of the workspace
+        char* pinned = nullptr;
+        if (use_cache && hipHostMalloc(reinterpret_cast<void**>(&pinned), region, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); pinned = nullptr; }
+        if (pinned) {
+            memcpy(pinned, blob.data(), region);
+            HIP_TRY(hipMemcpyAsync(base, pinned, region, hipMemcpyHostToDevice, stream));
+            MeshCacheEntry c;
+            c.fp = fp; c.dev = dev_now; c.pinned = pinned; c.bytes = region; c.base0 = (uintptr_t)base; c.k = k;
+            c.lds_bytes = ks->opt[e].mesh_lds_bytes; c.star_lds_bytes = ks->opt[e].mesh_star_lds_bytes;
+            c.ct_lds_bytes = ks->opt[e].mesh_ct_lds_bytes; c.dir_bytes = ks->opt[e].mesh_dir_bytes;
+            std::lock_guard<std::mutex> lock(g_mesh_mu);
+            c.used = ++g_mesh_tick;
+            if (g_mesh_cache.size() >= 8) {
+                // (the least recently used entry makes room; its pinned bytes may still feed a copy another thread queued a
+                //  moment ago: they are released only after that device's work has drained -- rare, and off the common path)
+                size_t old = 0;
+                for (size_t i = 1; i < g_mesh_cache.size(); i++) if (g_mesh_cache[i].used < g_mesh_cache[old].used) old = i;
+                (void)hipDeviceSynchronize();
+                (void)hipHostFree(g_mesh_cache[old].pinned);
+                g_mesh_cache[old] = c;
+            } else g_mesh_cache.push_back(c);
+        } else {
+            HIP_TRY(hipStreamSynchronize(stream));
+            HIP_TRY(hipMemcpy(base, blob.data(), region, hipMemcpyHostToDevice));
+        }
+        base += region;
     }
     return 0;
 }
