@@ -203,7 +203,8 @@ def test_segmented_runs_equal_reference(name, segments, route, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('route', ['split', 'split_tables_in_global', 'split_every_face', 'split_batches', 'split_list_walk', 'fused'])
+@pytest.mark.parametrize('route', ['split', 'split_tables_in_global', 'split_every_face', 'split_batches', 'split_list_walk', 'split_own_origins',
+                                   'fused'])
 @pytest.mark.parametrize('name', ['E_cfg5_mesh_flat_1e5', 'E_cfg5_mesh_interp_1e5', 'E_mesh_interp_counts', 'E_mesh_norefine_counts',
                                   'E_mesh_81_coarse17_counts', 'E_cfg5_wide_flat_1e5', 'E_cfg5_wide_interp_1e5', 'E_cfg5_wide_norefine_1e5'])
 def test_mesh_crystal_routes_equal_reference(name, route, monkeypatch):
@@ -218,6 +219,8 @@ def test_mesh_crystal_routes_equal_reference(name, route, monkeypatch):
     if route == 'split_every_face':
         monkeypatch.setenv('XICSRT_NO_DIR_GRID', '1')
     cfg, gold = helpers.load_golden(name)
+    if route == 'split_own_origins':                                # every parked ray keeps its origin in its record (as behind an extended source)
+        monkeypatch.setenv('XICSRT_NO_SHARED_ORIGIN', '1')
     if route == 'split_list_walk':                                  # without the fans: every parked ray walks its point's face list
         monkeypatch.setenv('XICSRT_NO_MESH_FANS', '1')
     config, elements, flat = helpers.build(cfg)

@@ -1163,6 +1163,10 @@ struct KArgs {
     // (split_interp != 0): the hit point in place of the origin (its height from the interpolation) and the interpolated
     // normal in components 6 - 8 (between the two middle launches component 6 holds the nearest point).
     uint32_t  split_interp;
+    // A mesh crystal straight behind a point source: every parked ray of the call has the same (local-frame) origin.  The first
+    // phase then leaves it ONCE per unit (unit_o[unit][3], from the unit's first parked ray -- the device's own arithmetic) and
+    // not in the records (24 of their 52 bytes); the middle launches and the second phase take it from there.  Null: per ray.
+    double*   unit_o;
     unsigned long long* dbg;            // development: [units][8] wall-clock stamps of a unit's phases (null: none)
     // Pixel bins of the fused kernel: `images` may point to image_rep replicas, image_stride bins apart, which the library
     // sums into the caller's bins behind the last launch.  Scattered 8-byte atomics execute at the memory side, and all
@@ -1356,7 +1360,9 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
     const int q_ncomp = q_wlc + (q_has_wl ? 1 : 0);
     auto cand_store = [&](int64_t i, const V3& o, const V3& d, double wl, uint32_t id, int aux) __attribute__((always_inline)) {
         double* c = cbase + (i >> 8) * (int64_t)(q_ncomp * 256) + (i & 255);
-        c[0 * 256] = o.x; c[1 * 256] = o.y; c[2 * 256] = o.z;
+        bool shared_o = false;
+        if constexpr (SPLIT) shared_o = args.unit_o != nullptr;
+        if (!shared_o) { c[0 * 256] = o.x; c[1 * 256] = o.y; c[2 * 256] = o.z; }
         c[3 * 256] = d.x; c[4 * 256] = d.y; c[5 * 256] = d.z;
         if (q_has_wl) c[q_wlc * 256] = wl;
         if (HIST) args.cand_id[crun + i] = id;
@@ -1364,7 +1370,10 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
     };
     auto cand_load = [&](int64_t i, V3& o, V3& d, double& wl, uint32_t& id, int& aux) __attribute__((always_inline)) {
         const double* c = cbase + (i >> 8) * (int64_t)(q_ncomp * 256) + (i & 255);
-        o.x = c[0 * 256]; o.y = c[1 * 256]; o.z = c[2 * 256];
+        // (split phases, a mesh that is not interpolated behind a point source: components 0 - 2 hold nothing, see KArgs.unit_o)
+        bool skip_o = false;
+        if constexpr (SPLIT) skip_o = args.unit_o != nullptr && !args.split_interp;
+        if (!skip_o) { o.x = c[0 * 256]; o.y = c[1 * 256]; o.z = c[2 * 256]; }
         d.x = c[3 * 256]; d.y = c[4 * 256]; d.z = c[5 * 256];
         wl = q_has_wl ? c[q_wlc * 256] : wl_run;
         id = HIST ? args.cand_id[crun + i] : 0u;
@@ -2027,6 +2036,12 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
                 uint32_t rank = wg_rank<true>(alive, wave_tot, slot, tid, n_a, rot_here);
                 if constexpr (SEG >= 2) {
                     if (alive) cand_store(ray_lo + (int64_t)(n_candidates + rank), X, ray.d, ray.wl, id, aux);
+                    if constexpr (SEG == 3) {
+                        if (args.unit_o && alive && n_candidates + rank == 0u) {        // (the unit's first parked ray)
+                            double* uo = args.unit_o + 3 * (size_t)unit;
+                            uo[0] = X.x; uo[1] = X.y; uo[2] = X.z;
+                        }
+                    }
                     n_candidates += n_a;
                 } else if constexpr (EXT) {
                     if (alive) {
@@ -2339,7 +2354,10 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
                                     if constexpr (SPLIT) {
                                         // (a mesh that is not interpolated: the record holds the ray's origin -- its hit point on the
                                         //  face, formed as the middle launches formed it)
-                                        if (!args.split_interp) X = mesh_hit_point(op.mesh, baux, ray);
+                                        if (!args.split_interp) {
+                                            if (args.unit_o) { const double* uo = args.unit_o + 3 * (size_t)unit; ray.o.x = uo[0]; ray.o.y = uo[1]; ray.o.z = uo[2]; }
+                                            X = mesh_hit_point(op.mesh, baux, ray);
+                                        }
                                     }
                                     ray.o = X;
                                     double dt = dot_e(ray.d, nrm);
@@ -2501,7 +2519,10 @@ void xrt_mesh_rest_kernel(const KScene* __restrict__ scene_g, const KArgs args, 
     if (have) {
         const int face = (int)args.cand_aux[crun + (size_t)i];
         int idx = -1;
-        const MeshHit h = mesh_rest_impl<false>(op.mesh, c[0 * 256], c[1 * 256], c[2 * 256], c[3 * 256], c[4 * 256], c[5 * 256], face, &idx);
+        // (the origin: the ray's own, or the one every parked ray of the unit has -- KArgs.unit_o)
+        const double* po = args.unit_o ? args.unit_o + 3 * (size_t)unit : nullptr;
+        const double ox = po ? po[0] : c[0 * 256], oy = po ? po[1] : c[1 * 256], oz = po ? po[2] : c[2 * 256];
+        const MeshHit h = mesh_rest_impl<false>(op.mesh, ox, oy, oz, c[3 * 256], c[4 * 256], c[5 * 256], face, &idx);
         V3 X;
         X.x = h.x; X.y = h.y; X.z = h.z;
         // (what is left of the ray: the face it ended on, or XRT_CAND_DEAD -- see KArgs.split_interp)
@@ -2595,7 +2616,9 @@ void xrt_mesh_rest_lds_kernel(const KScene* __restrict__ scene_g, const KArgs ar
             int idx;
             V3 nrm;
             nrm.x = nrm.y = nrm.z = 0.0;
-            const MeshHit h = mesh_rest_lds(Mp, L, c[0 * 256], c[1 * 256], c[2 * 256], c[3 * 256], c[4 * 256], c[5 * 256], face, idx, nrm);
+            const double* po = args.unit_o ? args.unit_o + 3 * (size_t)unit : nullptr;
+            const double ox = po ? po[0] : c[0 * 256], oy = po ? po[1] : c[1 * 256], oz = po ? po[2] : c[2 * 256];
+            const MeshHit h = mesh_rest_lds(Mp, L, ox, oy, oz, c[3 * 256], c[4 * 256], c[5 * 256], face, idx, nrm);
             V3 X;
             X.x = h.x; X.y = h.y; X.z = h.z;
             if constexpr (DEFER) {
@@ -2739,15 +2762,18 @@ void xrt_mesh_star_lds_kernel(const KScene* __restrict__ scene_g, const KArgs ar
         int fa = 0, fb = 0;
 #pragma unroll
         for (int q = 0; q < 6; q++) { ra[q] = 0.0; rb[q] = 0.0; }
+        const int q0 = args.unit_o ? 3 : 0;            // (behind a point source the origin is the unit's, KArgs.unit_o)
         if (A.have) {
 #pragma unroll
-            for (int q = 0; q < 6; q++) ra[q] = A.c[q * 256];
+            for (int q = 0; q < 6; q++) if (q >= q0) ra[q] = A.c[q * 256];
             fa = (int)args.cand_aux[A.crun + (size_t)(A.ray_lo + (int64_t)A.k)];
+            if (args.unit_o) { const double* uo = args.unit_o + 3 * (size_t)A.unit; ra[0] = uo[0]; ra[1] = uo[1]; ra[2] = uo[2]; }
         }
         if (B.have) {
 #pragma unroll
-            for (int q = 0; q < 6; q++) rb[q] = B.c[q * 256];
+            for (int q = 0; q < 6; q++) if (q >= q0) rb[q] = B.c[q * 256];
             fb = (int)args.cand_aux[B.crun + (size_t)(B.ray_lo + (int64_t)B.k)];
+            if (args.unit_o) { const double* uo = args.unit_o + 3 * (size_t)B.unit; rb[0] = uo[0]; rb[1] = uo[1]; rb[2] = uo[2]; }
         }
         work(A, ra, fa);
         if (ib < items) work(B, rb, fb);
@@ -3467,9 +3493,14 @@ static size_t mesh_split_off_items(const xrt_scene_t* sc, int n_runs, const SegP
 {
     return mesh_split_off_unit_slow(sc, n_runs, p) + al256(sizeof(uint32_t) * (size_t)n_runs * (size_t)p.n_seg * (size_t)p.n_sub);
 }
-static size_t mesh_split_end(const xrt_scene_t* sc, int n_runs, const SegPlan& p)
+// (... and the units' shared origins, KArgs.unit_o)
+static size_t mesh_split_off_unit_o(const xrt_scene_t* sc, int n_runs, const SegPlan& p)
 {
     return mesh_split_off_items(sc, n_runs, p) + 2 * al256(16 * mesh_split_items_max(sc, n_runs, p)) + 256;
+}
+static size_t mesh_split_end(const xrt_scene_t* sc, int n_runs, const SegPlan& p)
+{
+    return mesh_split_off_unit_o(sc, n_runs, p) + al256(24 * (size_t)n_runs * (size_t)p.n_seg * (size_t)p.n_sub) + 256;
 }
 static size_t cand_bytes(const xrt_scene_t* sc, int n_runs, size_t budget)
 {
@@ -4978,6 +5009,12 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
             a.unit_slow = reinterpret_cast<uint32_t*>(cb + mesh_split_off_unit_slow(sc, n_runs, plan));
             a.slow_pass = 0;
             a.split_interp = (sc->optics[be].mesh && sc->optics[be].mesh->interpolate) ? 1u : 0u;
+            {   // the mesh straight behind a source without extent: one origin for every parked ray (KArgs.unit_o)
+                const xrt_source_t& src = sc->source;
+                const bool point = be == 0 && (src.kind == XRT_SRC_GENERIC || src.kind == XRT_SRC_DIRECTED) && src.spatial_dist == XRT_SPATIAL_UNIFORM &&
+                                   src.size[0] == 0.0 && src.size[1] == 0.0 && src.size[2] == 0.0 && !env_on("XICSRT_NO_SHARED_ORIGIN");
+                a.unit_o = point ? reinterpret_cast<double*>(cb + mesh_split_off_unit_o(sc, n_runs, plan)) : nullptr;
+            }
             a.cand_cap = (int64_t)cand_capacity(sc);
             a.unit_flag = d_cnt;
             HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(uint32_t) * (size_t)n_runs * (size_t)S * (size_t)M, stream));
