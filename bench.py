@@ -19,6 +19,9 @@ propagation kernel, measured with HIP events on the launch stream inside the
 library (xrt_timing_begin/end).  `cpu_baseline` = the CPU oracle
 (oracle/xrt_oracle.c, a port of the reference's xicsrt_multiprocessing path)
 timed on the host cores on a bounded sample of the same workload, rank 0, N=1.
+`raytrace_call_ms` / `raytrace_call_object_construction_ms` (the user-level
+xicsrt_amd.raytrace(config) call of the same scene, outside the timed region) are
+measured at N=1 without a process group only; in multi-GPU lines they are null.
 """
 import argparse
 import ctypes as C
@@ -246,6 +249,10 @@ def main():
                 line['roofline']['limiter'] = 'valu_issue (see roofline_valu); HBM carries only the histogram atomics'
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(flat, args.rays)
+        # the real limiter first: `roofline_valu` (vector issue) in front of the BASELINE-defined HBM roofline
+        head = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+                'roofline_valu', 'roofline')
+        line = {**{k: line[k] for k in head if k in line}, **{k: v for k, v in line.items() if k not in head}}
         print(json.dumps(line))
     if use_dist:
         dist.destroy_process_group()
