@@ -819,6 +819,11 @@ __device__ __forceinline__ bool bragg_accept(const KOptic& op, const Ray& ray, c
         bool decided;
         const bool acc = bragg_screen(op, c, test, decided);
         if (decided) return acc;
+    } else if (op.scr2_ok && !have_bragg && test > 0.0) {
+        // (a ray with its own wavelength: the same screen through sin(inc - bragg), see bragg_screen_wl)
+        bool decided;
+        const bool acc = bragg_screen_wl(op, c, ray.wl, test, decided);
+        if (decided) return acc;
     }
     // ---- exact evaluation, in the reference's order -----------------------------------------------------
     // a monochromatic source gives every ray the same asin argument: evaluated once per run
@@ -3646,7 +3651,8 @@ static void bragg_screen(const xrt_source_t& src, KOptic& q)
     q.scr_s = q.scr_a1 = q.scr_a2 = q.scr_a3 = q.scr_binv = q.scr_dmax = 0.0;
     q.scr_ptail = INFINITY;
     q.scr2_ok = 0; q.scr2_tail = INFINITY; q.inv_two_d = 0.0;
-    if (q.interact != XRT_INTERACT_CRYSTAL || !(q.flags & XRT_F_CHECK_BRAGG)) return;
+    // (a mosaic crystal's layers make the same test with the crystallite's normal: optics/_InteractMosaicCrystal.py:96-103)
+    if ((q.interact != XRT_INTERACT_CRYSTAL && q.interact != XRT_INTERACT_MOSAIC) || !(q.flags & XRT_F_CHECK_BRAGG)) return;
     const double R = q.reflectivity;
     if (!(R >= 0.0) || !std::isfinite(R)) return;
     // rays with their own wavelength: |sin(inc - bragg)| >= 0.01 must put p below every non-zero deviate
@@ -4274,6 +4280,7 @@ static int upload_meshes(const xrt_scene_t* sc, char* ws, int n_runs, KScene* ks
                 for (size_t si = 0; si < T; si++)
                     simplex_of.emplace(sorted3((uint64_t)m->ct_simplices[3 * si], (uint64_t)m->ct_simplices[3 * si + 1], (uint64_t)m->ct_simplices[3 * si + 2]), (int32_t)si);
                 std::vector<int32_t> fs(F, -1);
+                std::vector<std::vector<int32_t>> around;          // the simplices at every point (made when first needed)
                 for (size_t i = 0; i < F; i++) {
                     const double* vs[3] = {m->p0 + 3 * i, m->p1 + 3 * i, m->p2 + 3 * i};
                     uint64_t pi[3];
@@ -4284,8 +4291,25 @@ static int upload_meshes(const xrt_scene_t* sc, char* ws, int n_runs, KScene* ks
                     }
                     if (!all) continue;
                     const auto it = simplex_of.find(sorted3(pi[0], pi[1], pi[2]));
-                    if (it != simplex_of.end()) fs[i] = it->second;
-                    else fs[i] = m->ct_vertex_simplex[pi[0]];          // (another triangulation: a simplex at one of the face's vertices)
+                    if (it != simplex_of.end()) { fs[i] = it->second; continue; }
+                    // Another triangulation of the same points (half of the quads of a regular grid get the other diagonal in x-y):
+                    // of the simplices at the face's vertices the one that holds the face's centroid -- a ray that ended on the
+                    // face is then in it or in the one across the diagonal, one step of the walk away.
+                    if (around.empty()) {
+                        around.resize(P);
+                        for (size_t si = 0; si < T; si++) for (int j = 0; j < 3; j++) around[(size_t)m->ct_simplices[3 * si + j]].push_back((int32_t)si);
+                    }
+                    const double gx = (vs[0][0] + vs[1][0] + vs[2][0]) / 3.0, gy = (vs[0][1] + vs[1][1] + vs[2][1]) / 3.0;
+                    int32_t best_s = m->ct_vertex_simplex[pi[0]];
+                    double best_c = -HUGE_VAL;
+                    for (int j = 0; j < 3; j++)
+                        for (int32_t si : around[pi[j]]) {
+                            const double* Tm = m->ct_transform + 6 * (size_t)si;
+                            const double c0 = Tm[0] * (gx - Tm[4]) + Tm[1] * (gy - Tm[5]), c1 = Tm[2] * (gx - Tm[4]) + Tm[3] * (gy - Tm[5]);
+                            const double cm = fmin(fmin(c0, c1), 1.0 - c0 - c1);
+                            if (cm > best_c) { best_c = cm; best_s = si; }
+                        }
+                    fs[i] = best_s;
                 }
                 k.face_simplex = (gip)put(fs.data(), F * 4);
             }
