@@ -410,7 +410,7 @@ int xrt_selftest_div3(const double* num, const double* den, int64_t n, uint64_t*
 
 /* Diagnostics: the device routes taken by this thread's xrt_trace / xrt_trace_history calls since the last
  * call with reset != 0 (bit set below).  The routes are picked per scene; the environment switches
- * XICSRT_NO_JUMP, XICSRT_NO_STAGE_SPLIT, XICSRT_STAGED_GAUSS, XICSRT_SEGMENTS force the fallbacks and are read
+ * XICSRT_NO_JUMP, XICSRT_NO_STAGE_SPLIT, XICSRT_STAGED_GAUSS, XICSRT_SEGMENTS, XICSRT_NO_MOSAIC_FUSED force the fallbacks and are read
  * at every call.  No reference counterpart. */
 #define XRT_PATH_FUSED          1u   /* source -> optics -> histogram in one kernel                    */
 #define XRT_PATH_STAGED         2u   /* array-at-a-time passes over a ray SoA in HBM                    */
@@ -424,6 +424,7 @@ int xrt_selftest_div3(const double* num, const double* den, int64_t n, uint64_t*
 #define XRT_PATH_ONE_PASS     512u   /* segmented runs in one pass: Bragg candidates parked in HBM, stream offsets by look-back */
 #define XRT_PATH_MESH_SPLIT   1024u  /* a mesh crystal: first phase, the rest of the mesh intersection per parked ray, second phase as three launches */
 #define XRT_PATH_MESH_FANS    2048u  /* ... the second pass over the faces around the nearest point first from that point's fan, the list walk for the rays left over */
+#define XRT_PATH_MOSAIC_FUSED 4096u  /* a mosaic crystal: the fused kernel's first phase parks the rays on the crystal, one kernel runs the layers and the elements behind over them */
 uint32_t xrt_last_path(int32_t reset);
 
 /* np.random.shuffle(np.arange(n))[:m] of numpy's legacy generator (host only, no device): what

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import logging
 logging.disable(logging.WARNING)
 import numpy as np, helpers
-from xicsrt_amd import xicsrt_raytrace as xrt
+from xicsrt_amd import xicsrt_raytrace as xrt, capi
 import test_gpu_scale as scale
 
 HISTORY = '--history' in sys.argv
@@ -21,6 +21,8 @@ def scene(rs):
     cfg = scale._random_scene(rs)
     cfg['sources']['source']['intensity'] = int(rs.choice([257, 5000, 40000, 150000]))
     kind = rs.randint(7)
+    if os.environ.get('FUZZ_KIND'):              # a sweep over one family of scenes (6: mosaic crystals)
+        kind = int(os.environ['FUZZ_KIND'])
     crystal = cfg['optics']['crystal']
     bragg = dict(crystal_spacing=2.45676, rocking_type=['gaussian', 'step'][rs.randint(2)],
                  rocking_fwhm=float(10 ** rs.uniform(-4.3, -2.0)))
@@ -56,7 +58,7 @@ def scene(rs):
                          'second': {'class_name': 'XicsrtOpticPlanarCrystal', 'origin': [0.0, 0.38, 0.69], 'zaxis': [0.0, -0.8, 0.6],
                                     'xsize': 0.5, 'ysize': 0.5, 'check_bragg': bool(rs.randint(2)), **bragg},
                          'detector': cfg['optics']['detector']}
-    elif kind == 6:     # mosaic crystals (the staged path: whole arrays of draws per layer)
+    elif kind == 6:     # mosaic crystals (the layers over parked rays, xrt_mosaic_kernel -- XICSRT_MOSAIC_FUSED_MIN=1 sends these small scenes there -- or the staged kernel)
         cls = ['XicsrtOpticPlanarMosaicCrystal', 'XicsrtOpticSphericalMosaicCrystal'][rs.randint(2)]
         c = {'class_name': cls, 'origin': CRYSTAL_AT, 'zaxis': ZAXIS, 'xsize': float(rs.uniform(0.05, 0.3)), 'ysize': float(rs.uniform(0.05, 0.3)),
              'mosaic_spread': float(np.radians(rs.uniform(0.05, 0.8))), 'mosaic_depth': int(rs.randint(1, 8)),
@@ -80,6 +82,7 @@ def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
     bad, skipped, paths, t0 = 0, 0, {}, time.time()
+    routes = {}              # xrt_last_path() of the counting call -> scenes (bits: include/xicsrt_hip.h XRT_PATH_*)
     outliers = []            # decisions equal, a position beyond 1e-9 (and inside the task's 1e-6): listed, not counted as mismatches
     for case in range(n_cases):
         rs = np.random.RandomState(seed0 + case)
@@ -110,8 +113,11 @@ def main():
             os.environ.pop(k, None)
         os.environ.update(env)
         dev = xrt.DeviceTrace(flat)
+        capi.lib().xrt_last_path(1)
         dev.trace(seeds, g['number_of_iter'])
         meta, image = dev.results()
+        route = int(capi.lib().xrt_last_path(1))
+        routes[route] = routes.get(route, 0) + 1
         n_gpu = np.array([int(meta[nm]['num_out']) for nm in flat.names])
         i_gpu = dev.images.cpu().numpy()
         key = cfg['optics']['crystal']['class_name'] + ' / ' + cfg['sources']['source']['class_name']
@@ -144,7 +150,8 @@ def main():
     # decision_mismatches: counters, pixels, masks, NaN patterns, stream positions or a position beyond 1e-6 -- must be 0;
     # position_outliers: all decisions equal, a position differs by 1e-9 .. 1e-6 relative (ill-conditioned lost rays)
     print(json.dumps({'cases': n_cases, 'first_seed': seed0, 'skipped': skipped, 'decision_mismatches': bad,
-                      'position_outliers': outliers, 'scenes': paths, 'seconds': time.time() - t0}))
+                      'position_outliers': outliers, 'scenes': paths, 'routes': {str(k): v for k, v in sorted(routes.items())},
+                      'seconds': time.time() - t0}))
 
 
 if __name__ == '__main__':

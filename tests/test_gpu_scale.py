@@ -645,3 +645,76 @@ def test_tail_pass_fits_the_workspace_on_a_narrow_grid(monkeypatch):
     got = np.concatenate([image[nm].ravel() for nm in flat.names[1:]]).astype(np.int64)
     assert np.array_equal(got, o_img[:flat.image_bins])
 
+
+
+@pytest.mark.parametrize('name', ['M_planar_mosaic_counts', 'M_spherical_mosaic_cutoff_1e5'])
+def test_mosaic_layers_over_parked_rays_equal_reference(name, monkeypatch):
+    """A mosaic crystal's layers over the rays the fused kernel's first phase parked (xrt_mosaic_kernel; scenes of at least
+    65536 rays by themselves, smaller ones when XICSRT_MOSAIC_FUSED_MIN says so) and the staged kernel are two routes to the
+    same integers: the reference's (optics/_InteractMosaicCrystal.py:53-139), runs x iterations and the cut-off included."""
+    from xicsrt_amd import capi
+    cfg, gold = helpers.load_golden(name)
+    config, elements, flat = helpers.build(cfg)
+    g = config['general']
+    seeds = xrt.run_seeds(g['random_seed'], g['number_of_runs'])
+    lib = capi.lib()
+    got = {}
+    for route in ('parked', 'staged'):
+        if route == 'parked':
+            monkeypatch.setenv('XICSRT_MOSAIC_FUSED_MIN', '1')
+        else:
+            monkeypatch.setenv('XICSRT_NO_MOSAIC_FUSED', '1')
+        dev = xrt.DeviceTrace(flat)
+        lib.xrt_last_path(1)
+        dev.trace(seeds, g['number_of_iter'], keep_images=True)
+        meta, image = dev.results()
+        path = lib.xrt_last_path(1)
+        if route == 'parked':
+            assert (path & capi.PATH_MOSAIC_FUSED) and not (path & capi.PATH_STAGED)
+        else:
+            assert (path & capi.PATH_STAGED) and not (path & capi.PATH_MOSAIC_FUSED)
+        for nm in flat.names:
+            assert int(meta[nm]['num_out']) == int(gold['num_out/' + nm]), (route, nm)
+        for nm in flat.names[1:]:
+            if image[nm] is not None:
+                assert np.array_equal(image[nm].astype(np.int64), gold['image/' + nm]), (route, nm)
+        got[route] = dev.images.cpu().numpy().copy()
+    assert np.array_equal(got['parked'], got['staged'])
+
+
+def test_mosaic_layers_over_parked_rays_random_scenes(monkeypatch):
+    """Random mosaic scenes (planar / spherical, cut-off, no Bragg test, extended and focused sources, wavelength
+    distributions, several runs and iterations) through xrt_mosaic_kernel: counts and images of the oracle."""
+    from xicsrt_amd import capi
+    import fuzz_parity
+    monkeypatch.setenv('FUZZ_KIND', '6')
+    monkeypatch.setenv('FUZZ_MAX_ITER', '3')
+    monkeypatch.setenv('FUZZ_MAX_RUNS', '5')
+    monkeypatch.setenv('XICSRT_MOSAIC_FUSED_MIN', '1')
+    lib = capi.lib()
+    taken = 0
+    for case in range(60):
+        rs = np.random.RandomState(880000 + case)
+        cfg = fuzz_parity.scene(rs)
+        cfg['optics']['crystal']['trace_local'] = False
+        cfg['sources']['source']['intensity'] = int(rs.choice([3000, 20000, 70000]))
+        try:
+            config, elements, flat = helpers.build(cfg)
+        except Exception:
+            continue
+        g = config['general']
+        seeds = xrt.run_seeds(g['random_seed'], g['number_of_runs'])
+        try:
+            n_cpu, i_cpu = helpers.oracle_counts(flat, seeds, g['number_of_iter'], threads=8)
+        except AssertionError:
+            continue
+        dev = xrt.DeviceTrace(flat)
+        lib.xrt_last_path(1)
+        dev.trace(seeds, g['number_of_iter'])
+        meta, image = dev.results()
+        path = lib.xrt_last_path(1)
+        taken += bool(path & capi.PATH_MOSAIC_FUSED)
+        n_gpu = np.array([int(meta[nm]['num_out']) for nm in flat.names])
+        assert np.array_equal(n_gpu, n_cpu), (case, n_gpu, n_cpu)
+        assert np.array_equal(dev.images.cpu().numpy()[:flat.image_bins], i_cpu[:flat.image_bins]), case
+    assert taken >= 20          # (sources with normal deviates or filters stay with the staged kernel)

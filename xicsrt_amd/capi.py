@@ -25,6 +25,7 @@ PATH_LDS_BINS = 256
 PATH_ONE_PASS = 512
 PATH_MESH_SPLIT = 1024
 PATH_MESH_FANS = 2048
+PATH_MOSAIC_FUSED = 4096
 
 _lib = None
 

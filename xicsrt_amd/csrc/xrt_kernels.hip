@@ -1240,7 +1240,9 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
     // registers allow); 4: Bragg test and the elements behind over what is left.  Neither compiles any of the mesh code
     // but the first pass: four workgroups per CU instead of two.
     constexpr bool PH_A = SEG != 4, PH_B = SEG != 3, SPLIT = SEG >= 3;
-    static_assert(!SPLIT || (VARIANT == 2 && !HIST), "split phases: mesh variant without histories only");
+    // (3 alone also in front of xrt_mosaic_kernel, variants 0 / 1: the rays on a mosaic crystal are parked and that is all)
+    static_assert(!SPLIT || !HIST, "split phases: without histories only");
+    static_assert(SEG != 4 || VARIANT == 2, "second phase of the split: mesh variant only");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     // One circular structure-of-arrays buffer of XRT_QCAP ray records serves as
     //  (a) the FIFO queue of rays waiting for the Bragg test (filled tile by tile in ray
@@ -1316,6 +1318,9 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
     int be = -1;
     for (int e = 0; e < SC.n_optics; e++)
         if (SC.opt[e].interact == XRT_INTERACT_CRYSTAL && (SC.opt[e].flags & XRT_F_CHECK_BRAGG)) be = e;
+    if constexpr (SEG == 3 && !EXT) {       // (in front of xrt_mosaic_kernel: the scene's one mosaic crystal)
+        for (int e = 0; e < SC.n_optics; e++) if (SC.opt[e].interact == XRT_INTERACT_MOSAIC) be = e;
+    }
     // A mesh crystal that makes the Bragg test: only the exhaustive first pass runs in a tile's own lanes (about half
     // of a cone of rays misses the mesh altogether, and a wave of unrelated rays executes the union of its lanes'
     // work); the rays that hit a face wait in the Bragg queue and get the rest -- nearest point, second pass,
@@ -2979,6 +2984,7 @@ void xrt_mesh_ct_lds_kernel(const KScene* __restrict__ scene_g, const KArgs args
 #undef SRC
 
 #include "xrt_staged.inc"
+#include "xrt_mosaic.inc"
 
 #define XRT_PLASMA_PART 2
 #include "xrt_plasma.inc"
@@ -4734,6 +4740,72 @@ static int launch_variant(const KScene* ks, const KArgs& a_in, int n_runs, size_
 
 // one iteration of every run: position the heads (jump-ahead when every stream is in the
 // canonical form and the arrays are long enough, else the sequential walk), then propagate
+// The unsegmented routes: every run's source heads at the first words of their arrays and the run's stream head behind the
+// source arrays (jump-ahead when every stream is in the canonical form, else the sequential walk).
+static int position_heads(const xrt_scene_t* sc, const KScene& ks, char* ws, int n_runs, int nh, int64_t N, bool canonical,
+                          KStream* streams, KStream* heads, hipStream_t stream)
+{
+    if (canonical && !env_on("XICSRT_NO_JUMP") && N >= (int64_t)XRT_AHEAD / 2) {
+        g_paths |= XRT_PATH_JUMP;
+        static thread_local std::vector<uint32_t> hpolys;
+        hpolys.clear();
+        int n_polys = 0;
+        for (int k = 1; k <= ks.src.n_arrays; k++) {
+            if (k < ks.src.n_arrays && !((ks.src.array_used >> k) & 1u)) continue;
+            hpolys.resize((size_t)(n_polys + 1) * 624);
+            const uint64_t J = 2ull * (uint64_t)k * (uint64_t)N - (uint64_t)XRT_AHEAD;
+            if (!mtjump::jump_poly(J, hpolys.data() + (size_t)n_polys * 624))
+                return fail(-5, "%s", "MT19937 characteristic polynomial could not be derived");
+            n_polys++;
+        }
+        uint32_t* d_polys = reinterpret_cast<uint32_t*>(ws + ws_off_polys(sc, n_runs));
+        HIP_TRY(hipMemcpyAsync(d_polys, hpolys.data(), sizeof(uint32_t) * 624 * (size_t)n_polys, hipMemcpyHostToDevice, stream));
+        const size_t jl = sizeof(uint32_t) * ((size_t)XRT_STRETCH + 48 + 624 + 624 * (size_t)n_polys);
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(xrt_jump_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)jl));
+        int dev = 0, cus = 256;
+        HIP_TRY(hipGetDevice(&dev));
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        int grid = n_runs < cus ? n_runs : cus;
+        hipLaunchKernelGGL(xrt_jump_kernel, dim3(grid), dim3(XRT_JUMP_THREADS), jl, stream, streams, heads, d_polys, n_runs,
+                           ks.src.n_arrays, ks.src.array_used, nh, n_polys, N);
+        HIP_TRY(hipGetLastError());
+    } else {
+        g_paths |= XRT_PATH_SEEK;
+        hipLaunchKernelGGL(xrt_seek_kernel, dim3((n_runs + 3) / 4), dim3(256), 0, stream,
+                           streams, heads, n_runs, ks.src.n_arrays, ks.src.array_used, nh, N);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
+// A mosaic crystal's layers over parked rays (xrt_mosaic.inc) instead of the staged kernel: one mosaic crystal of an analytic
+// shape in the global frame, no other Bragg test, no mesh and no local frame anywhere, an ordinary source whose draws have a
+// fixed length; the parked rays and the layers' draws of ALL runs in the staged path's slots (as many slots as runs).
+static bool mosaic_fused_ok(const xrt_scene_t* sc, int n_runs, bool hist)
+{
+    if (hist || env_on("XICSRT_NO_MOSAIC_FUSED")) return false;
+    const xrt_source_t& s = sc->source;
+    if (s.kind == XRT_SRC_PLASMA || s.kind == XRT_SRC_EXTERNAL || s.n_ray_filters > 0) return false;
+    if (s.spatial_dist == XRT_SPATIAL_GAUSSIAN || s.angular_dist == XRT_ANG_ISOTROPIC_XY || s.wavelength_dist == XRT_WL_NORMAL) return false;
+    // (runs of few rays: the staged kernel's few passes are as good, and a record block of 256 per run does not fit its slot;
+    //  XICSRT_MOSAIC_FUSED_MIN: the tests send small scenes this way)
+    long long least = 65536;
+    if (const char* e = getenv("XICSRT_MOSAIC_FUSED_MIN")) { const long long v = atoll(e); if (v >= 1) least = v; }
+    if (s.intensity < least) return false;
+    {
+        const bool has_wl = !(s.wavelength_dist == XRT_WL_CONST && !s.has_velocity);
+        if (cand_capacity(sc) * (8 * (size_t)(has_wl ? 7 : 6) + 32) + 16 > staged_slot_bytes(sc)) return false;
+    }
+    int n_mosaic = 0;
+    for (int e = 0; e < sc->n_optics; e++) {
+        const xrt_optic_t& o = sc->optics[e];
+        if (o.interact == XRT_INTERACT_MOSAIC) n_mosaic++;
+        if (o.interact == XRT_INTERACT_CRYSTAL && (o.flags & XRT_F_CHECK_BRAGG)) return false;
+    }
+    if (n_mosaic != 1 || needs_ext(sc)) return false;
+    return staged_slots(sc, n_runs) == n_runs;
+}
+
 // `ahead`: words every stream head has generated beyond `next` when this is called (XRT_AHEAD: the
 // canonical form between kernels; 624: an imported state after xrt_advance_kernel; 0: unknown)
 static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size_t ws_bytes, KArgs a, int n_runs, bool hist,
@@ -4793,6 +4865,70 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
         }
         return 0;
     }
+#ifndef XRT_DEV_ONLY_LEAN
+    if (!force_staged && mosaic_fused_ok(sc, n_runs, hist)) {
+        // ---- a mosaic crystal: the fused kernel's first phase parks the rays on the crystal, xrt_mosaic_kernel does the rest
+        g_paths |= XRT_PATH_FUSED | XRT_PATH_MOSAIC_FUSED;
+        {
+            const int st = position_heads(sc, ks, ws, n_runs, nh, N, canonical, streams, heads, stream);
+            if (st) return st;
+        }
+        int be = -1;
+        for (int e = 0; e < sc->n_optics; e++) if (sc->optics[e].interact == XRT_INTERACT_MOSAIC) be = e;
+        const bool has_wl = !(ks.src.wavelength_dist == XRT_WL_CONST && !ks.src.has_velocity);
+        const int ncomp = has_wl ? 7 : 6;
+        const size_t cap = cand_capacity(sc);
+        // (the arena: the staged path's slots, one per run -- staged_slot_bytes >= what a run takes here)
+        char* base = ws + ws_off_staged(sc, n_runs);
+        const size_t per_run = cap * (8 * (size_t)ncomp + 4 + 24 + 4);
+        if (per_run + 16 > staged_slot_bytes(sc)) return fail(-5, "%s", "mosaic route: slot too small");
+        KMosaic mo;
+        memset(&mo, 0, sizeof(mo));
+        char* p = base;
+        mo.cand = reinterpret_cast<double*>(p);  p += (size_t)n_runs * cap * 8 * (size_t)ncomp;
+        mo.draws = reinterpret_cast<double*>(p); p += (size_t)n_runs * cap * 24;
+        mo.list = reinterpret_cast<uint32_t*>(p); p += (size_t)n_runs * cap * 4;
+        mo.mark = reinterpret_cast<uint32_t*>(p); p += (size_t)n_runs * cap * 4;
+        // (the runs' counts: in the staged path's per-slot words behind the slots -- 16 bytes per slot)
+        uint32_t* d_flag = reinterpret_cast<uint32_t*>(base + (size_t)n_runs * (staged_slot_bytes(sc) - 16));
+        if ((char*)d_flag < p) return fail(-5, "%s", "mosaic route: slot layout");
+        mo.n_cand = d_flag;
+        mo.gauss_state = reinterpret_cast<KState*>(ws + ws_off_gauss(sc, n_runs));
+        mo.cap = (int64_t)cap; mo.be = be; mo.ncomp = ncomp;
+        HIP_TRY(hipMemsetAsync(d_flag, 0, sizeof(uint32_t) * (size_t)n_runs, stream));
+        a.streams = streams; a.heads = heads; a.n_runs = n_runs; a.n_src_heads = nh;
+        a.run_counter = reinterpret_cast<uint32_t*>(ws);
+        a.progress = env_on("XICSRT_NO_PRIORITY_FEEDBACK") ? nullptr : reinterpret_cast<unsigned long long*>(ws + 32);
+        // first phase: every run one unit (one segment, one part), the plain layout of the heads
+        const int64_t Lr = (N + XRT_TILE - 1) / XRT_TILE * XRT_TILE;
+        a.n_seg = 1; a.seg_len = Lr; a.n_sub = 1; a.sub_len = Lr; a.run_stride = nh; a.mode = 2;
+        a.chunk_heads = nullptr; a.chunk_words = 1;
+        a.cand = mo.cand; a.cand_id = nullptr; a.cand_aux = nullptr; a.cand_cap = (int64_t)cap; a.unit_flag = d_flag;
+        a.unit_o = nullptr; a.split_interp = 0; a.dir_lds_bytes = 0;
+        a.qcap = XRT_TILE; a.bragg_batch = 128u;
+        const size_t lds3 = lds_bytes(nh, false, false, has_wl, XRT_TILE);
+        HIP_TRY(hipMemsetAsync(ws, 0, 64, stream));
+        int st = needs_full(sc) ? launch_variant<false, 1, 3>(device_scene(ws), a, n_runs, lds3, stream)
+                                : launch_variant<false, 0, 3>(device_scene(ws), a, n_runs, lds3, stream);
+        if (st) return st;
+        // the layers and the elements behind the crystal: a workgroup per run
+        KArgs am = a;
+        if (am.image_rep > 1u && am.images) am.images = am.images_rep;
+        const size_t lds_mo = sizeof(uint32_t) * (XRT_PC_RING + XRT_PC_MIRROR + 4u + 2 * (XRT_DEV_MAX_OPTICS + 2) + 8 + XRT_PC_CTL + 4);
+        int ti = -1;
+        if (timing_on && timing_n < TIMING_MAX) {
+            ti = timing_n++;
+            HIP_TRY(hipEventCreate(&timing_ev[ti][0]));
+            HIP_TRY(hipEventCreate(&timing_ev[ti][1]));
+            HIP_TRY(hipEventRecord(timing_ev[ti][0], stream));
+        }
+        HIP_TRY(hipMemsetAsync(ws, 0, 64, stream));
+        hipLaunchKernelGGL(xrt_mosaic_kernel, dim3((unsigned)(n_runs < 1024 ? n_runs : 1024)), dim3(XRT_TILE), lds_mo, stream, device_scene(ws), am, mo);
+        HIP_TRY(hipGetLastError());
+        if (ti >= 0) HIP_TRY(hipEventRecord(timing_ev[ti][1], stream));
+        return 0;
+    }
+#endif
 #ifdef XRT_DEV_ONLY_LEAN
     if (needs_staged(sc) || force_staged) return fail(-3, "%s", "development build: lean kernel only");
 #else
@@ -4818,6 +4954,8 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
         if (a.image_rep > 1u && a.images) a.images = a.images_rep;      // (the replicas of the bins, summed behind the call's last launch)
         HIP_TRY(hipMemsetAsync(ws, 0, 64, stream));
         const size_t lds = sizeof(double) * XRT_TILE_COMP * XRT_TILE + sizeof(uint32_t) * (2 * XRT_TILE + XRT_RING + 16 + 2 * (XRT_DEV_MAX_OPTICS + 2) + 16);
+        // (the instances that run a mosaic crystal's layers with the waves in roles -- ST_PC -- have the larger ring and the hand-over words)
+        const size_t lds_pc = lds + sizeof(uint32_t) * (XRT_PC_RING + XRT_PC_MIRROR + 4u - XRT_RING + XRT_PC_CTL + 4);
         int ti = -1;
         if (timing_on && timing_n < TIMING_MAX) {
             ti = timing_n++;
@@ -4857,7 +4995,7 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
                 hipLaunchKernelGGL(k1, dim3(grid1), dim3(XRT_TILE), lds, stream, device_scene(ws), a, g);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipMemsetAsync(ws, 0, 64, stream));
-                hipLaunchKernelGGL(k2, dim3(grid2), dim3(XRT_TILE), lds, stream, device_scene(ws), a, g);
+                hipLaunchKernelGGL(k2, dim3(grid2), dim3(XRT_TILE), (has_mesh || special) ? lds_pc : lds, stream, device_scene(ws), a, g);
                 HIP_TRY(hipGetLastError());
             }
             if (ti >= 0) HIP_TRY(hipEventRecord(timing_ev[ti][1], stream));
@@ -4869,7 +5007,7 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
                                   : (special ? xrt_staged_kernel<true, 0, 2> : xrt_staged_kernel<true, 0, 0>);
         else      kern = src == 1 ? (special ? xrt_staged_kernel<false, 1, 2> : xrt_staged_kernel<false, 1, 0>)
                                   : (special ? xrt_staged_kernel<false, 0, 2> : xrt_staged_kernel<false, 0, 0>);
-        hipLaunchKernelGGL(kern, dim3(slots), dim3(XRT_TILE), lds, stream, device_scene(ws), a, g);
+        hipLaunchKernelGGL(kern, dim3(slots), dim3(XRT_TILE), (special && !hist) ? lds_pc : lds, stream, device_scene(ws), a, g);
         HIP_TRY(hipGetLastError());
         if (ti >= 0) HIP_TRY(hipEventRecord(timing_ev[ti][1], stream));
         return 0;
@@ -5203,35 +5341,9 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
         return 0;
     }
     g_paths |= XRT_PATH_FUSED;
-    if (canonical && !env_on("XICSRT_NO_JUMP") && N >= (int64_t)XRT_AHEAD / 2) {
-        g_paths |= XRT_PATH_JUMP;
-        static thread_local std::vector<uint32_t> hpolys;
-        hpolys.clear();
-        int n_polys = 0;
-        for (int k = 1; k <= ks.src.n_arrays; k++) {
-            if (k < ks.src.n_arrays && !((ks.src.array_used >> k) & 1u)) continue;
-            hpolys.resize((size_t)(n_polys + 1) * 624);
-            const uint64_t J = 2ull * (uint64_t)k * (uint64_t)N - (uint64_t)XRT_AHEAD;
-            if (!mtjump::jump_poly(J, hpolys.data() + (size_t)n_polys * 624))
-                return fail(-5, "%s", "MT19937 characteristic polynomial could not be derived");
-            n_polys++;
-        }
-        uint32_t* d_polys = reinterpret_cast<uint32_t*>(ws + ws_off_polys(sc, n_runs));
-        HIP_TRY(hipMemcpyAsync(d_polys, hpolys.data(), sizeof(uint32_t) * 624 * (size_t)n_polys, hipMemcpyHostToDevice, stream));
-        const size_t jl = sizeof(uint32_t) * ((size_t)XRT_STRETCH + 48 + 624 + 624 * (size_t)n_polys);
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(xrt_jump_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)jl));
-        int dev = 0, cus = 256;
-        HIP_TRY(hipGetDevice(&dev));
-        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        int grid = n_runs < cus ? n_runs : cus;
-        hipLaunchKernelGGL(xrt_jump_kernel, dim3(grid), dim3(XRT_JUMP_THREADS), jl, stream, streams, heads, d_polys, n_runs,
-                           ks.src.n_arrays, ks.src.array_used, nh, n_polys, N);
-        HIP_TRY(hipGetLastError());
-    } else {
-        g_paths |= XRT_PATH_SEEK;
-        hipLaunchKernelGGL(xrt_seek_kernel, dim3((n_runs + 3) / 4), dim3(256), 0, stream,
-                           streams, heads, n_runs, ks.src.n_arrays, ks.src.array_used, nh, N);
-        HIP_TRY(hipGetLastError());
+    {
+        const int st = position_heads(sc, ks, ws, n_runs, nh, N, canonical, streams, heads, stream);
+        if (st) return st;
     }
     a.streams = streams; a.heads = heads; a.n_runs = n_runs; a.n_src_heads = nh;
     a.run_counter = reinterpret_cast<uint32_t*>(ws);
