@@ -13,7 +13,11 @@ flat = xrt.Elements(config).flatten()
 seeds = xrt.run_seeds(5, runs)
 dev = xrt.DeviceTrace(flat)
 dev.trace(seeds, 1); dev.results()
+dev._ws[128:208].zero_()
 t0 = time.time(); dev.trace(seeds, 1); dev.results(); dt = time.time() - t0
-w = dev._ws[128:160].cpu().numpy().view(np.uint64)
+w = dev._ws[128:208].cpu().numpy().view(np.uint64)
 print(json.dumps({'runs': runs, 'call_ms': dt * 1e3, 'gauss_ms_per_wg': float(w[0]) / 1e5 / runs, 'uniform_ms_per_wg': float(w[1]) / 1e5 / runs,
-                  'pass_ms_per_wg': float(w[2]) / 1e5 / runs, 'ray_layers': int(w[3])}))
+                  'pass_ms_per_wg': float(w[2]) / 1e5 / runs, 'ray_layers_per_run': int(w[3]) // runs,
+                  'list_ms_per_wg': float(w[4]) / 1e5 / runs, 'behind_ms_per_wg': float(w[5]) / 1e5 / runs,
+                  'generator_sleeps_per_run': int(w[6]) // runs, 'generator_steps_per_run': int(w[7]) // runs,
+                  'tester_word_waits_per_run': int(w[8]) // runs, 'tester_chain_waits_per_run': int(w[9]) // runs}))

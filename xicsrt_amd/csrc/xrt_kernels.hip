@@ -819,12 +819,15 @@ __device__ __forceinline__ bool bragg_accept(const KOptic& op, const Ray& ray, c
         bool decided;
         const bool acc = bragg_screen(op, c, test, decided);
         if (decided) return acc;
-    } else if (op.scr2_ok && !have_bragg && test > 0.0) {
+    }
+#ifndef XRT_DEV_NO_WL_SCREEN
+    else if (op.scr2_ok && !have_bragg && test > 0.0) {
         // (a ray with its own wavelength: the same screen through sin(inc - bragg), see bragg_screen_wl)
         bool decided;
         const bool acc = bragg_screen_wl(op, c, ray.wl, test, decided);
         if (decided) return acc;
     }
+#endif
     // ---- exact evaluation, in the reference's order -----------------------------------------------------
     // a monochromatic source gives every ray the same asin argument: evaluated once per run
     double bragg = have_bragg ? bragg_shared : asin(ray.wl / op.two_d);
@@ -4895,6 +4898,7 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
         mo.n_cand = d_flag;
         mo.gauss_state = reinterpret_cast<KState*>(ws + ws_off_gauss(sc, n_runs));
         mo.cap = (int64_t)cap; mo.be = be; mo.ncomp = ncomp;
+        mo.dbg = reinterpret_cast<unsigned long long*>(ws + XRT_WS_STATUS_BYTE + 64);     // (development builds: the header's spare words)
         HIP_TRY(hipMemsetAsync(d_flag, 0, sizeof(uint32_t) * (size_t)n_runs, stream));
         a.streams = streams; a.heads = heads; a.n_runs = n_runs; a.n_src_heads = nh;
         a.run_counter = reinterpret_cast<uint32_t*>(ws);
@@ -4953,7 +4957,7 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
         a.run_counter = reinterpret_cast<uint32_t*>(ws);
         if (a.image_rep > 1u && a.images) a.images = a.images_rep;      // (the replicas of the bins, summed behind the call's last launch)
         HIP_TRY(hipMemsetAsync(ws, 0, 64, stream));
-        const size_t lds = sizeof(double) * XRT_TILE_COMP * XRT_TILE + sizeof(uint32_t) * (2 * XRT_TILE + XRT_RING + 16 + 2 * (XRT_DEV_MAX_OPTICS + 2) + 16);
+        const size_t lds = sizeof(double) * XRT_TILE_COMP * XRT_TILE + sizeof(uint32_t) * (2 * XRT_TILE + XRT_RING + 16 + 2 * (XRT_DEV_MAX_OPTICS + 2) + 16 + XRT_ST_FSPEC);
         // (the instances that run a mosaic crystal's layers with the waves in roles -- ST_PC -- have the larger ring and the hand-over words)
         const size_t lds_pc = lds + sizeof(uint32_t) * (XRT_PC_RING + XRT_PC_MIRROR + 4u - XRT_RING + XRT_PC_CTL + 4);
         int ti = -1;
