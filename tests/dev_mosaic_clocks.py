@@ -12,12 +12,14 @@ config = xconfig.get_config(config)
 flat = xrt.Elements(config).flatten()
 seeds = xrt.run_seeds(5, runs)
 dev = xrt.DeviceTrace(flat)
-dev.trace(seeds, 1); dev.results()
-dev._ws[128:208].zero_()
-t0 = time.time(); dev.trace(seeds, 1); dev.results(); dt = time.time() - t0
-w = dev._ws[128:208].cpu().numpy().view(np.uint64)
+images = os.environ.get('NO_IMAGES') is None
+dev.trace(seeds, 1, keep_images=images); dev.results()
+dev._ws[128:224].zero_()
+t0 = time.time(); dev.trace(seeds, 1, keep_images=images); dev.results(); dt = time.time() - t0
+w = dev._ws[128:224].cpu().numpy().view(np.uint64)
 print(json.dumps({'runs': runs, 'call_ms': dt * 1e3, 'gauss_ms_per_wg': float(w[0]) / 1e5 / runs, 'uniform_ms_per_wg': float(w[1]) / 1e5 / runs,
                   'pass_ms_per_wg': float(w[2]) / 1e5 / runs, 'ray_layers_per_run': int(w[3]) // runs,
                   'list_ms_per_wg': float(w[4]) / 1e5 / runs, 'behind_ms_per_wg': float(w[5]) / 1e5 / runs,
                   'generator_sleeps_per_run': int(w[6]) // runs, 'generator_steps_per_run': int(w[7]) // runs,
-                  'tester_word_waits_per_run': int(w[8]) // runs, 'tester_chain_waits_per_run': int(w[9]) // runs}))
+                  'tester_word_waits_per_run': int(w[8]) // runs, 'tester_chain_waits_per_run': int(w[9]) // runs,
+                  'behind_load_ms_wave0': float(w[10]) / 1e5 / runs, 'behind_work_ms_wave0': float(w[11]) / 1e5 / runs}))

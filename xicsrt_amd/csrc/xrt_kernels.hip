@@ -1372,6 +1372,13 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
     const int q_wlc = (SPLIT && args.split_interp) ? 9 : 6;
     const int q_ncomp = q_wlc + (q_has_wl ? 1 : 0);
     auto cand_store = [&](int64_t i, const V3& o, const V3& d, double wl, uint32_t id, int aux) __attribute__((always_inline)) {
+        if constexpr (SEG == 3 && !EXT) {
+            // (in front of xrt_mosaic_kernel: a record in one piece -- its layers read single rays of a thinning list)
+            double* r = cbase + i * (int64_t)q_ncomp;
+            r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d.x; r[4] = d.y; r[5] = d.z;
+            if (q_has_wl) r[6] = wl;
+            return;
+        }
         double* c = cbase + (i >> 8) * (int64_t)(q_ncomp * 256) + (i & 255);
         bool shared_o = false;
         if constexpr (SPLIT) shared_o = args.unit_o != nullptr;
