@@ -19,6 +19,6 @@ probe "XICSRT_PLASMA_STAGED=1" "tests/bench_plasma.py 4096"     # ... through th
 probe "" "tests/bench_staged.py"                        # np.random.normal wavelengths, prepared
 probe "XICSRT_STAGED_GAUSS=1" "tests/bench_staged.py"   # ... through the staged kernels
 probe "" "tests/bench_cfg5.py 1000 1000000 2"           # BASELINE cfg5 at full size, flat and interpolated mesh
-probe "" "tests/bench_mosaic.py 1000 1000000"           # mosaic crystal, 15 layers (staged path), at the bench size
+probe "" "tests/bench_mosaic.py 1000 1000000"           # mosaic crystal, 15 layers (parked rays + xrt_mosaic_kernel), at the bench size
 probe "" "tests/bench_mosaic.py 256 1000000"            # ... and at 256 runs (one workgroup per CU: the latency of one run's chain of steps)
 probe "" "tests/bench_history.py"                       # raytrace(config) with keep_history, as notebooks call it

@@ -2702,14 +2702,23 @@ void xrt_mesh_star_lds_kernel(const KScene* __restrict__ scene_g, const KArgs ar
     const bool q_has_wl = !(SRC.wavelength_dist == XRT_WL_CONST && !SRC.has_velocity);
     const int q_ncomp = (args.split_interp ? 9 : 6) + (q_has_wl ? 1 : 0);
     const uint32_t upr = (uint32_t)args.n_seg * (uint32_t)args.n_sub;
-    // Two blocks per round: a block's records are read once, ~2 us after they are asked for, and sixteen waves per CU do not
-    // cover that; with the records of two blocks asked for up front the second block's arrive while the first is worked on.
+    // One block (1024 records, 64 per wave) per round, in this order: (1) the item of the NEXT block -- asked for a round ago --
+    // is taken up, (2) what the round BEFORE found is stored, (3) the next block's records and the item of the block after
+    // are asked for, (4) this block's arithmetic.  Loads and stores count in one vmcnt, in order, and how many stores a round
+    // issues depends on its rays: a round can only wait for "all" -- here all of it was asked for a block's arithmetic ago.
+    // (Stores behind the arithmetic and the next item / records in front of it cost three memory round trips per round:
+    // 0.55 - 0.65 of the vector issue rate with two blocks per round.)
     struct Block { uint32_t unit, k, n_unit; size_t crun; int64_t ray_lo; double* c; bool have; };
+    struct Rec { double r[6]; int face; };
+    struct Found { bool settled, alive, slow; uint32_t aux; int idx; V3 X; unsigned long long sl, ab; };
     const uint32_t items = uni32(*args.n_items);
-    auto locate = [&](uint32_t it, Block& B) __attribute__((always_inline)) -> uint32_t {
-        // item `it` of the list of the blocks that hold rays (beyond its end: returns `items`)
+    auto item_ask = [&](uint32_t it) __attribute__((always_inline)) -> uint4 {
+        return args.items[it < items ? it : (items > 0u ? items - 1u : 0u)];
+    };
+    auto locate = [&](uint32_t it, const uint4& item, Block& B) __attribute__((always_inline)) {
+        // item `it` of the list of the blocks that hold rays (beyond its end: nothing to do)
+        B.have = false; B.unit = 0; B.k = 0; B.n_unit = 0; B.crun = 0; B.ray_lo = 0; B.c = args.cand;
         if (it < items) {
-            const uint4 item = args.items[it];
             const uint32_t unit = uni32(item.x), blk = uni32(item.y), n_unit = uni32(item.z);
             const uint32_t run = unit / upr, uidx = unit - run * upr;
             const uint32_t seg = uidx / (uint32_t)args.n_sub, sub = uidx - seg * (uint32_t)args.n_sub;
@@ -2723,82 +2732,99 @@ void xrt_mesh_star_lds_kernel(const KScene* __restrict__ scene_g, const KArgs ar
             const int64_t i = ray_lo + (int64_t)B.k;
             B.c = args.cand + B.crun * (size_t)q_ncomp + (i >> 8) * (int64_t)(q_ncomp * 256) + (i & 255);
             B.have = B.k < n_unit;
-            return it;
         }
-        B.have = false; B.unit = 0; B.k = 0; B.n_unit = 0; B.crun = 0; B.ray_lo = 0; B.c = args.cand;
-        return items;
     };
-    auto work = [&](const Block& B, const double* r, int face) __attribute__((always_inline)) {
-        const uint32_t unit = B.unit, k = B.k, n_unit = B.n_unit;
-        const size_t crun = B.crun;
-        const int64_t ray_lo = B.ray_lo, i = ray_lo + (int64_t)k;
-        double* c = B.c;
-        bool alive = false, slow = false;
+    const int q0 = args.unit_o ? 3 : 0;                // (behind a point source the origin is the unit's, KArgs.unit_o)
+    auto ask = [&](const Block& B, Rec& R) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 6; q++) R.r[q] = 0.0;
+        R.face = 0;
         if (B.have) {
-            int idx;
+#pragma unroll
+            for (int q = 0; q < 6; q++) if (q >= q0) R.r[q] = B.c[q * 256];
+            R.face = (int)args.cand_aux[B.crun + (size_t)(B.ray_lo + (int64_t)B.k)];
+            if (args.unit_o) { const double* uo = args.unit_o + 3 * (size_t)B.unit; R.r[0] = uo[0]; R.r[1] = uo[1]; R.r[2] = uo[2]; }
+        }
+    };
+    auto work = [&](const Block& B, const Rec& R) __attribute__((always_inline)) -> Found {
+        Found F;
+        F.settled = false; F.alive = false; F.slow = false; F.aux = 0u; F.idx = 0;
+        F.X.x = F.X.y = F.X.z = 0.0;
+        if (B.have) {
             V3 nrm;
             nrm.x = nrm.y = nrm.z = 0.0;
-            const MeshHit h = mesh_rest_star_lds(Mp, L, r[0], r[1], r[2], r[3], r[4], r[5], face, idx, nrm, slow);
+            bool slow = false;
+            const MeshHit h = mesh_rest_star_lds(Mp, L, R.r[0], R.r[1], R.r[2], R.r[3], R.r[4], R.r[5], R.face, F.idx, nrm, slow);
+            F.slow = slow;
             if (!slow) {
-                V3 X;
-                X.x = h.x; X.y = h.y; X.z = h.z;
-                if constexpr (DEFER) {
-                    c[0 * 256] = X.x; c[1 * 256] = X.y; c[2 * 256] = X.z;
-                    c[6 * 256] = __hiloint2double(0, idx);
-                    args.cand_aux[crun + (size_t)i] = (uint32_t)h.aux;
-                } else {
-                    alive = check_bounds<true>(op, X);
-                    args.cand_aux[crun + (size_t)i] = alive ? (uint32_t)h.aux : XRT_CAND_DEAD;
+                F.settled = true;
+                F.X.x = h.x; F.X.y = h.y; F.X.z = h.z;
+                F.aux = (uint32_t)h.aux;
+                if constexpr (!DEFER) {
+                    F.alive = check_bounds<true>(op, F.X);
+                    if (!F.alive) F.aux = XRT_CAND_DEAD;
                 }
             }
         }
         // the rays left for the list walk: their numbers within the unit
 #ifdef XRT_DEV_NO_SLOWQ
-        const unsigned long long sl = 0ULL;
+        F.sl = 0ULL;
 #else
-        const unsigned long long sl = __ballot(slow);
+        F.sl = __ballot(F.slow);
 #endif
+        F.ab = __ballot(F.alive);
+        return F;
+    };
+    auto put = [&](const Block& B, const Found& F) __attribute__((always_inline)) {
+        const uint32_t unit = B.unit, k = B.k, n_unit = B.n_unit;
+        const size_t crun = B.crun;
+        const int64_t ray_lo = B.ray_lo, i = ray_lo + (int64_t)k;
+        if (F.settled) {
+            if constexpr (DEFER) {
+                double* c = B.c;
+                c[0 * 256] = F.X.x; c[1 * 256] = F.X.y; c[2 * 256] = F.X.z;
+                c[6 * 256] = __hiloint2double(0, F.idx);
+            }
+            args.cand_aux[crun + (size_t)i] = F.aux;
+        }
         // (per 64 records -- this wave's -- and without atomics: a counter per unit that every wave of the chip adds to and
         //  waits for cost 4 ms of the launch's 27)
-        if (slow) args.slow_q[crun + (size_t)ray_lo + (k & ~63u) + __builtin_amdgcn_mbcnt_hi((uint32_t)(sl >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sl, 0u))] = k;
-        if ((tid & 63) == 0 && 64u * (k >> 6) < ((n_unit + 63u) & ~63u)) args.slow_cnt[((crun + (size_t)ray_lo) >> 6) + (k >> 6)] = (uint32_t)__popcll(sl);
+        if (F.slow) args.slow_q[crun + (size_t)ray_lo + (k & ~63u) + __builtin_amdgcn_mbcnt_hi((uint32_t)(F.sl >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)F.sl, 0u))] = k;
+        const bool in_unit = n_unit > 0u && 64u * (k >> 6) < ((n_unit + 63u) & ~63u);
+        if ((tid & 63) == 0 && in_unit) args.slow_cnt[((crun + (size_t)ray_lo) >> 6) + (k >> 6)] = (uint32_t)__popcll(F.sl);
         if constexpr (!DEFER) {
-            const unsigned long long ab = __ballot(alive);
-            if ((tid & 63) == 0 && 64u * (k >> 6) < ((n_unit + 63u) & ~63u)) {
-                const uint32_t n = (uint32_t)__popcll(ab);
+            if ((tid & 63) == 0 && in_unit) {
+                const uint32_t n = (uint32_t)__popcll(F.ab);
                 args.batch_alive[((crun + (size_t)ray_lo) >> 6) + (k >> 6)] = n;
                 if (n) atomicAdd(&args.unit_alive[unit], n);
             }
         }
     };
     uint32_t it = blockIdx.x;
-    for (;;) {
-        Block A, B;
-        const uint32_t ia = locate(it, A);
-        if (ia >= items) break;
-        const uint32_t ib = locate(ia + gridDim.x, B);
-        // both blocks' records: asked for here, used below
-        double ra[6], rb[6];
-        int fa = 0, fb = 0;
-#pragma unroll
-        for (int q = 0; q < 6; q++) { ra[q] = 0.0; rb[q] = 0.0; }
-        const int q0 = args.unit_o ? 3 : 0;            // (behind a point source the origin is the unit's, KArgs.unit_o)
-        if (A.have) {
-#pragma unroll
-            for (int q = 0; q < 6; q++) if (q >= q0) ra[q] = A.c[q * 256];
-            fa = (int)args.cand_aux[A.crun + (size_t)(A.ray_lo + (int64_t)A.k)];
-            if (args.unit_o) { const double* uo = args.unit_o + 3 * (size_t)A.unit; ra[0] = uo[0]; ra[1] = uo[1]; ra[2] = uo[2]; }
-        }
-        if (B.have) {
-#pragma unroll
-            for (int q = 0; q < 6; q++) if (q >= q0) rb[q] = B.c[q * 256];
-            fb = (int)args.cand_aux[B.crun + (size_t)(B.ray_lo + (int64_t)B.k)];
-            if (args.unit_o) { const double* uo = args.unit_o + 3 * (size_t)B.unit; rb[0] = uo[0]; rb[1] = uo[1]; rb[2] = uo[2]; }
-        }
-        work(A, ra, fa);
-        if (ib < items) work(B, rb, fb);
-        it = ib + gridDim.x;
+    if (it >= items) return;
+    Block Bc, Bp;
+    Rec Rc;
+    Found Fp;
+    uint4 raw_n;
+    {
+        const uint4 raw_c = item_ask(it);
+        raw_n = item_ask(it + gridDim.x);
+        locate(it, raw_c, Bc);
+        ask(Bc, Rc);
     }
+    locate(items, raw_n, Bp);                            // (nothing found yet: a block without rays)
+    Fp = work(Bp, Rc);
+    for (; it < items; it += gridDim.x) {
+        Block Bn;
+        Rec Rn;
+        locate(it + gridDim.x, raw_n, Bn);
+        put(Bp, Fp);
+        ask(Bn, Rn);
+        raw_n = item_ask(it + 2u * gridDim.x);
+        Fp = work(Bc, Rc);
+        Bp = Bc; Bc = Bn; Rc = Rn;
+    }
+    put(Bp, Fp);
 }
 
 // The blocks of 1024 records that hold rays (KArgs.items), units in order: counts[u] - minus records in unit u.
