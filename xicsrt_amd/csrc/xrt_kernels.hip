@@ -875,6 +875,27 @@ __device__ __forceinline__ void image_hit_lds(const KOptic& op, const V3& X, uin
     }
 }
 
+// The same 16-bit counters where nothing bounds how many hits a counter takes between two flushes (xrt_mosaic_kernel: the
+// reflected rays of a whole run): the lane whose add takes a counter from 0x7fff to 0x8000 -- exactly one per crossing -- moves
+// 0x8000 hits on into the u64 bin.  (Up to 255 more adds may land before its subtraction does: no carry into the neighbour.)
+__device__ __forceinline__ void image_hit_lds_spill(const KOptic& op, const V3& X, uint32_t* lbins, unsigned long long* images)
+{
+    V3 loc = to_local(op.R, sub3(X, ld3(op.origin)));
+    double cx = rint(loc.x / op.pixel_size + op.pixel_xoff);
+    double cy = rint(loc.y / op.pixel_size + op.pixel_yoff);
+    if (cx >= 0.0 && cx < (double)op.pixel_nx && cy >= 0.0 && cy < (double)op.pixel_ny) {
+        typedef __attribute__((address_space(3))) uint32_t l32;
+        const uint32_t p = (uint32_t)(op.image_offset + (long long)cx * op.pixel_ny + (long long)cy);
+        const uint32_t sh = (p & 1u) << 4;
+        l32* const w = (l32*)lbins + (p >> 1);
+        const uint32_t old = __hip_atomic_fetch_add(w, 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (((old >> sh) & 0xffffu) == 0x7fffu) {
+            __hip_atomic_fetch_sub(w, 0x8000u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            atomicAdd(&images[p], 0x8000ULL);
+        }
+    }
+}
+
 // --------------------------------------------------------------------------
 // workgroup scan: ordered rank of `flag` among the 256 threads (wave64 ballot,
 // mbcnt, 4 wave totals through LDS).  One barrier; `slot` alternates so that
@@ -4951,7 +4972,12 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
         // the layers and the elements behind the crystal: a workgroup per run
         KArgs am = a;
         if (am.image_rep > 1u && am.images) am.images = am.images_rep;
-        const size_t lds_mo = sizeof(uint32_t) * (XRT_PC_RING + XRT_PC_MIRROR + 4u + 2 * (XRT_DEV_MAX_OPTICS + 2) + 8 + XRT_PC_CTL + 4);
+        // (pixel bins in LDS for the reflected rays, where the scene's bins fit 40 KB of LDS together with the rest -- four
+        //  workgroups per CU -- as 16-bit counters: they take the place of the ring, which is done by then, and what they need beyond)
+        const uint32_t ring_words = XRT_PC_RING + XRT_PC_MIRROR + 4u, small_words = 2 * (XRT_DEV_MAX_OPTICS + 2) + 8 + XRT_PC_CTL + 4;
+        uint32_t bins_words = (am.images && sc->image_bins > 0 && sc->image_bins <= 19000 && !env_on("XICSRT_NO_LDS_BINS")) ? (uint32_t)((sc->image_bins + 1) / 2) : 0u;
+        mo.lbins_words = bins_words;
+        const size_t lds_mo = sizeof(uint32_t) * ((size_t)small_words + (bins_words > ring_words ? bins_words : ring_words));
         int ti = -1;
         if (timing_on && timing_n < TIMING_MAX) {
             ti = timing_n++;
