@@ -718,3 +718,30 @@ def test_mosaic_layers_over_parked_rays_random_scenes(monkeypatch):
         assert np.array_equal(n_gpu, n_cpu), (case, n_gpu, n_cpu)
         assert np.array_equal(dev.images.cpu().numpy()[:flat.image_bins], i_cpu[:flat.image_bins]), case
     assert taken >= 20          # (sources with normal deviates or filters stay with the staged kernel)
+
+
+def test_mosaic_pixel_counters_in_lds_spill_into_the_bins(monkeypatch):
+    """xrt_mosaic_kernel counts the reflected rays' pixel hits in 16-bit LDS counters; the lane whose add takes a counter to 0x8000
+    moves 0x8000 hits on into the u64 bin.  Images of a few coarse pixels: > 1e5 hits per counter and run, several crossings."""
+    import bench
+    from xicsrt_amd import capi
+    cfg = bench.spectrometer_config(200000, 3, seed=11)
+    cfg['optics']['crystal'].update(class_name='XicsrtOpticSphericalMosaicCrystal', mosaic_spread=float(np.radians(0.4)), mosaic_depth=8,
+                                    rocking_fwhm=2e-3, pixel_size=0.2)
+    cfg['optics']['detector'].update(pixel_size=0.4)
+    config = xconfig.get_config(cfg)
+    flat = xrt.Elements(config).flatten()
+    assert flat.image_bins < 64
+    seeds = xrt.run_seeds(11, 3)
+    n_cpu, i_cpu = helpers.oracle_counts(flat, seeds, 1, threads=3)
+    assert i_cpu[:flat.image_bins].max() > 6 * 0x8000         # (three runs: each takes its counter over 0x8000 at least twice)
+    for lds_bins in (True, False):
+        if not lds_bins:
+            monkeypatch.setenv('XICSRT_NO_LDS_BINS', '1')
+        dev = xrt.DeviceTrace(flat)
+        capi.lib().xrt_last_path(1)
+        dev.trace(seeds, 1)
+        meta, image = dev.results()
+        assert capi.lib().xrt_last_path(1) & capi.PATH_MOSAIC_FUSED
+        assert [int(meta[nm]['num_out']) for nm in flat.names] == [int(v) for v in n_cpu]
+        assert np.array_equal(dev.images.cpu().numpy()[:flat.image_bins], i_cpu[:flat.image_bins]), lds_bins
