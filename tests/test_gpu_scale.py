@@ -210,7 +210,8 @@ def test_segmented_runs_equal_reference(name, segments, route, monkeypatch):
 def test_mesh_crystal_routes_equal_reference(name, route, monkeypatch):
     """A mesh crystal that makes the Bragg test goes through three launches -- rays up to the first pass over the faces
     (behind a point source: through the grid over the directions), the rest of ShapeMesh.intersect per parked ray (small
-    meshes: tables in LDS, faces classified from their vertices; interpolation in a launch of its own), Bragg test and
+    meshes: tables in LDS, faces classified from their vertices; first from the fan of faces around the nearest point, with the
+    tables in LDS or in global memory; interpolation in a launch of its own), Bragg test and
     the elements behind.  Every variant of it, and the one-kernel route, give the reference's integers."""
     if route == 'fused':
         monkeypatch.setenv('XICSRT_NO_MESH_SPLIT', '1')
@@ -245,10 +246,10 @@ def test_mesh_crystal_routes_equal_reference(name, route, monkeypatch):
             assert np.array_equal(image[nm].astype(np.int64), gold['image/' + nm]), nm
     path = capi.lib().xrt_last_path(1)
     assert bool(path & capi.PATH_MESH_SPLIT) == (route != 'fused'), (path, route)
-    if route in ('split_list_walk', 'split_tables_in_global', 'fused') or name in ('E_mesh_norefine_counts', 'E_mesh_81_coarse17_counts',
-                                                                                   'E_cfg5_wide_norefine_1e5'):
-        assert not (path & capi.PATH_MESH_FANS), (path, route)          # (no coarse level / tables beyond the LDS: no fans)
+    if route in ('split_list_walk', 'fused') or name in ('E_mesh_norefine_counts', 'E_cfg5_wide_norefine_1e5'):
+        assert not (path & capi.PATH_MESH_FANS), (path, route)          # (no coarse level: no fans)
     else:
+        # (also with the tables in global memory -- a mesh beyond the LDS, 81 x 81 points, or XICSRT_NO_MESH_LDS: xrt_mesh_star_kernel)
         assert path & capi.PATH_MESH_FANS, (path, route)
 
 

@@ -200,7 +200,7 @@ struct KOptic {
     int32_t mesh_lds_bytes;             // host side: KMesh.lds_bytes of `mesh` (which launch finishes a split mesh intersection)
     int32_t mesh_dir_bytes;             // host side: LDS bytes of the mesh's direction grid (KMesh.dg_n), 0: none
     int32_t mesh_ct_lds_bytes;          // host side: bytes of the mesh's Clough-Tocher vertex table when it fits the LDS (xrt_mesh_ct_lds_kernel), else 0
-    int32_t mesh_star_lds_bytes;        // host side: KMesh.star_lds_bytes of `mesh` (0: no fans, the list walk for every parked ray)
+    int32_t mesh_star_lds_bytes;        // host side: KMesh.star_lds_bytes of `mesh` (0: no fans, the list walk for every parked ray; < 0: fans, read from global memory)
     int32_t pad_star;
 };
 
@@ -2692,33 +2692,13 @@ void xrt_mesh_rest_lds_kernel(const KScene* __restrict__ scene_g, const KArgs ar
 // finished here -- DEFER as above --, the others keep their records untouched and are listed per unit for the launch that
 // walks the lists (xrt_mesh_rest_lds_kernel / xrt_mesh_rest_kernel with slow_pass).  Tables in LDS: the buckets of the
 // points (also the vertex table), the fans, the faces of the first pass.
-template <bool DEFER>
-__global__ __launch_bounds__(XRT_MESH_LDS_THREADS)
-void xrt_mesh_star_lds_kernel(const KScene* __restrict__ scene_g, const KArgs args, int be)
+template <bool DEFER, class LT>
+__device__ __forceinline__ void mesh_star_blocks(const KScene* __restrict__ scene_g, const KArgs& args, int be, const LT& L)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const KScene* scl = scene_fresh(scene_g);
     const KOptic& op = SC.opt[be];
     const KMesh* Mp = op.mesh;
-    MeshRef M = *(const XRT_C4 KMesh*)uniform_u64((uint64_t)Mp);
     const int tid = threadIdx.x;
-    const uint32_t nc = (uint32_t)M.n_cells, np = (uint32_t)M.n_points, n1 = (uint32_t)M.n_first + 1u;
-    d4v* l_cells = reinterpret_cast<d4v*>(lds_raw);
-    uint32_t* l_star = reinterpret_cast<uint32_t*>(l_cells + nc);              // [np][12] words
-    double* l_first = reinterpret_cast<double*>(l_star + 12u * np);
-    {
-        const XRT_G1 d4v* g = M.cells;
-        for (uint32_t i = (uint32_t)tid; i < nc; i += XRT_MESH_LDS_THREADS) l_cells[i] = g[i];
-        const XRT_G1 uint32_t* gs = (const XRT_G1 uint32_t*)(uint64_t)M.lds_star;
-        for (uint32_t i = (uint32_t)tid; i < 12u * np; i += XRT_MESH_LDS_THREADS) l_star[i] = gs[i];
-        const XRT_G1 double* g1 = (const XRT_G1 double*)(uint64_t)M.first_rec;
-        for (uint32_t i = (uint32_t)tid; i < 10u * n1; i += XRT_MESH_LDS_THREADS) l_first[i] = g1[i];
-    }
-    __syncthreads();
-    MeshStarLds L;
-    L.cells = (lcell)l_cells;
-    L.star = (const XRT_LDS3 uint16_t*)l_star;
-    L.first = (const XRT_LDS3 double*)l_first;
     const int64_t N = SRC.n_rays;
     const bool q_has_wl = !(SRC.wavelength_dist == XRT_WL_CONST && !SRC.has_velocity);
     const int q_ncomp = (args.split_interp ? 9 : 6) + (q_has_wl ? 1 : 0);
@@ -2846,6 +2826,53 @@ void xrt_mesh_star_lds_kernel(const KScene* __restrict__ scene_g, const KArgs ar
         Bp = Bc; Bc = Bn; Rc = Rn;
     }
     put(Bp, Fp);
+}
+
+template <bool DEFER>
+__global__ __launch_bounds__(XRT_MESH_LDS_THREADS)
+void xrt_mesh_star_lds_kernel(const KScene* __restrict__ scene_g, const KArgs args, int be)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const KScene* scl = scene_fresh(scene_g);
+    const KOptic& op = SC.opt[be];
+    const KMesh* Mp = op.mesh;
+    MeshRef M = *(const XRT_C4 KMesh*)uniform_u64((uint64_t)Mp);
+    const int tid = threadIdx.x;
+    const uint32_t nc = (uint32_t)M.n_cells, np = (uint32_t)M.n_points, n1 = (uint32_t)M.n_first + 1u;
+    d4v* l_cells = reinterpret_cast<d4v*>(lds_raw);
+    uint32_t* l_star = reinterpret_cast<uint32_t*>(l_cells + nc);              // [np][12] words
+    double* l_first = reinterpret_cast<double*>(l_star + 12u * np);
+    {
+        const XRT_G1 d4v* g = M.cells;
+        for (uint32_t i = (uint32_t)tid; i < nc; i += XRT_MESH_LDS_THREADS) l_cells[i] = g[i];
+        const XRT_G1 uint32_t* gs = (const XRT_G1 uint32_t*)(uint64_t)M.lds_star;
+        for (uint32_t i = (uint32_t)tid; i < 12u * np; i += XRT_MESH_LDS_THREADS) l_star[i] = gs[i];
+        const XRT_G1 double* g1 = (const XRT_G1 double*)(uint64_t)M.first_rec;
+        for (uint32_t i = (uint32_t)tid; i < 10u * n1; i += XRT_MESH_LDS_THREADS) l_first[i] = g1[i];
+    }
+    __syncthreads();
+    MeshStarLds L;
+    L.cells = (lcell)l_cells;
+    L.star = (const XRT_LDS3 uint16_t*)l_star;
+    L.first = (const XRT_LDS3 double*)l_first;
+    mesh_star_blocks<DEFER>(scene_g, args, be, L);
+}
+
+// The same for a mesh whose tables do not fit the LDS (81 x 81 points: 210 KB of buckets alone): the fans, the buckets and the
+// first pass' faces read where they lie in global memory (~1 MB: they stay in the L2).  A gather costs the L1 a tag lookup per
+// lane and 16 bytes, so a ray is dearer here than with the tables in LDS -- but it is ONE face's test instead of the walk over
+// the <= 8 faces of the list, and the rays the fans cannot settle are few.
+template <bool DEFER>
+__global__ __launch_bounds__(XRT_MESH_LDS_THREADS)
+void xrt_mesh_star_kernel(const KScene* __restrict__ scene_g, const KArgs args, int be)
+{
+    const KScene* scl = scene_fresh(scene_g);
+    MeshRef M = *(const XRT_C4 KMesh*)uniform_u64((uint64_t)SC.opt[be].mesh);
+    MeshStarT<TabGlobal> L;
+    L.cells = M.cells;
+    L.star = (const XRT_G1 uint16_t*)(uint64_t)M.lds_star;
+    L.first = (const XRT_G1 double*)(uint64_t)M.first_rec;
+    mesh_star_blocks<DEFER>(scene_g, args, be, L);
 }
 
 // The blocks of 1024 records that hold rays (KArgs.items), units in order: counts[u] - minus records in unit u.
@@ -4452,7 +4479,10 @@ static int upload_meshes(const xrt_scene_t* sc, char* ws, int n_runs, KScene* ks
                 k.n_cells = (int32_t)cells.size();
                 const size_t n_first = (size_t)k.n_first;
                 const size_t lds_need = cells.size() * sizeof(KCellRec) + P * 16 + F * 8 + (n_first + 1) * 80 + 64;
-                if (F < 0xffff && cells.size() < 0xffff && lds_need <= XRT_MESH_LDS_MAX && !env_on("XICSRT_NO_MESH_LDS")) {
+                // (the tables of 16-bit numbers: for the LDS forms, and -- the fans -- also for a mesh that does not fit the LDS,
+                //  read from global memory then: star_lds_bytes < 0)
+                const bool lds_ok = lds_need <= XRT_MESH_LDS_MAX && !env_on("XICSRT_NO_MESH_LDS");
+                if (F < 0xffff && cells.size() < 0xffff && (lds_ok || !env_on("XICSRT_NO_MESH_FANS"))) {
                     struct Key { uint64_t a, b, c; bool operator==(const Key& o) const { return a == o.a && b == o.b && c == o.c; } };
                     struct KeyHash { size_t operator()(const Key& q) const { return (size_t)(q.a * 0x9e3779b97f4a7c15ull ^ (q.b + 0x7f4a7c15ull) * 0xbf58476d1ce4e5b9ull ^ (q.c * 0x94d049bb133111ebull)); } };
                     std::unordered_map<Key, int32_t, KeyHash> where;
@@ -4475,14 +4505,14 @@ static int upload_meshes(const xrt_scene_t* sc, char* ws, int n_runs, KScene* ks
                                 const int32_t f = m->p_faces_idx[(size_t)j * P + i];
                                 if (f < 0 || (size_t)f >= F) all = false; else pf16[8 * i + j] = (uint16_t)f;
                             }
-                    if (all) {
+                    if (all && lds_ok) {
                         k.lds_pf = (const uint16_t*)put(pf16.data(), pf16.size() * 2);
                         k.lds_fv = (const uint16_t*)put(fv.data(), fv.size() * 2);
                         k.lds_bytes = (int32_t)lds_need;
                     }
                     // ---- the faces around every point as a fan (KMesh.lds_star, mesh_rest_star_lds) ------------------
                     const size_t star_need = cells.size() * sizeof(KCellRec) + P * 48 + (n_first + 1) * 80 + 64;
-                    if (all && star_need <= XRT_MESH_LDS_MAX && !env_on("XICSRT_NO_MESH_FANS")) {
+                    if (all && !env_on("XICSRT_NO_MESH_FANS")) {
                         auto sub = [](const double* a, const double* b, double* o) { o[0] = a[0] - b[0]; o[1] = a[1] - b[1]; o[2] = a[2] - b[2]; };
                         auto crs = [](const double* a, const double* b, double* o) { o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0]; };
                         auto dot = [](const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
@@ -4607,7 +4637,7 @@ static int upload_meshes(const xrt_scene_t* sc, char* ws, int n_runs, KScene* ks
                             }
                             if (n_fans > 0) {
                                 k.lds_star = (const uint16_t*)put(star.data(), star.size() * 2);
-                                k.star_lds_bytes = (int32_t)star_need;
+                                k.star_lds_bytes = (lds_ok && star_need <= XRT_MESH_LDS_MAX) ? (int32_t)star_need : -1;
                                 k.star_K = starK;
                                 k.star_c2 = (2.0 * spread + 0.05) * (2.0 * spread + 0.05);
                             }
@@ -5322,7 +5352,9 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
             // the work of the launches with tables in LDS: the blocks of 1024 records that hold rays (KArgs.items)
             uint4* d_items = nullptr;
             uint32_t* d_nitems = nullptr;
-            if (lds_m > 0 || lds_ct > 0) {
+            const int lds_st = ks.opt[be].mesh_star_lds_bytes;
+            const bool fans_lds = lds_m > 0 && lds_st > 0, fans_glb = !fans_lds && lds_st != 0;
+            if (lds_m > 0 || lds_ct > 0 || fans_glb) {
                 char* cb = ws + ws_base_bytes(sc, n_runs);
                 d_items = reinterpret_cast<uint4*>(cb + mesh_split_off_items(sc, n_runs, plan));
                 d_nitems = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(d_items) + 2 * al256(16 * mesh_split_items_max(sc, n_runs, plan)));
@@ -5331,8 +5363,12 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
                 am.items = d_items; am.n_items = d_nitems;
             }
             // a mesh with fans: what one face of the nearest point's fan settles first, the launch below for the rays left over
-            const int lds_st = ks.opt[be].mesh_star_lds_bytes;
-            if (lds_m > 0 && lds_st > 0) {
+            if (fans_lds || fans_glb) {
+                if (fans_glb) {
+                    // (a mesh beyond the LDS: the same launch over the tables in global memory)
+                    if (ct) hipLaunchKernelGGL((xrt_mesh_star_kernel<true>), dim3(grid), dim3(XRT_MESH_LDS_THREADS), 0, stream, device_scene(ws), am, be);
+                    else    hipLaunchKernelGGL((xrt_mesh_star_kernel<false>), dim3(grid), dim3(XRT_MESH_LDS_THREADS), 0, stream, device_scene(ws), am, be);
+                } else
                 if (ct) {
                     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(xrt_mesh_star_lds_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_st));
                     hipLaunchKernelGGL((xrt_mesh_star_lds_kernel<true>), dim3(grid), dim3(XRT_MESH_LDS_THREADS), (size_t)lds_st, stream, device_scene(ws), am, be);
