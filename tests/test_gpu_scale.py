@@ -681,6 +681,18 @@ def test_mosaic_layers_over_parked_rays_equal_reference(name, monkeypatch):
                 assert np.array_equal(image[nm].astype(np.int64), gold['image/' + nm]), (route, nm)
         got[route] = dev.images.cpu().numpy().copy()
     assert np.array_equal(got['parked'], got['staged'])
+    if g['number_of_runs'] >= 2:
+        # a budget that holds one run's slot: the parked-ray route goes through the runs in batches
+        monkeypatch.delenv('XICSRT_NO_MOSAIC_FUSED')
+        monkeypatch.setenv('XICSRT_WORKSPACE_BUDGET_MB', str(max(1, int(flat.n_rays * 92 * 1.5) >> 20)))
+        dev = xrt.DeviceTrace(flat)
+        lib.xrt_last_path(1)
+        dev.trace(seeds, g['number_of_iter'], keep_images=True)
+        meta, image = dev.results()
+        assert lib.xrt_last_path(1) & capi.PATH_MOSAIC_FUSED
+        for nm in flat.names:
+            assert int(meta[nm]['num_out']) == int(gold['num_out/' + nm]), ('batches', nm)
+        assert np.array_equal(dev.images.cpu().numpy(), got['parked'])
 
 
 def test_mosaic_layers_over_parked_rays_random_scenes(monkeypatch):

@@ -4867,7 +4867,7 @@ static int position_heads(const xrt_scene_t* sc, const KScene& ks, char* ws, int
 
 // A mosaic crystal's layers over parked rays (xrt_mosaic.inc) instead of the staged kernel: one mosaic crystal of an analytic
 // shape in the global frame, no other Bragg test, no mesh and no local frame anywhere, an ordinary source whose draws have a
-// fixed length; the parked rays and the layers' draws of ALL runs in the staged path's slots (as many slots as runs).
+// fixed length; the parked rays and the layers' draws in the staged path's slots, a run per slot, the runs in batches of the slots.
 static bool mosaic_fused_ok(const xrt_scene_t* sc, int n_runs, bool hist)
 {
     if (hist || env_on("XICSRT_NO_MOSAIC_FUSED")) return false;
@@ -4889,8 +4889,8 @@ static bool mosaic_fused_ok(const xrt_scene_t* sc, int n_runs, bool hist)
         if (o.interact == XRT_INTERACT_MOSAIC) n_mosaic++;
         if (o.interact == XRT_INTERACT_CRYSTAL && (o.flags & XRT_F_CHECK_BRAGG)) return false;
     }
-    if (n_mosaic != 1 || needs_ext(sc)) return false;
-    return staged_slots(sc, n_runs) == n_runs;
+    (void)n_runs;           // (more runs than the staged path has slots: batches)
+    return n_mosaic == 1 && !needs_ext(sc);
 }
 
 // `ahead`: words every stream head has generated beyond `next` when this is called (XRT_AHEAD: the
@@ -4965,26 +4965,27 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
         const bool has_wl = !(ks.src.wavelength_dist == XRT_WL_CONST && !ks.src.has_velocity);
         const int ncomp = has_wl ? 7 : 6;
         const size_t cap = cand_capacity(sc);
-        // (the arena: the staged path's slots, one per run -- staged_slot_bytes >= what a run takes here)
+        // (the arena: the staged path's slots, one per run of a batch -- staged_slot_bytes >= what a run takes here; a call
+        //  with more runs than slots -- 1024, or what the budget holds -- goes through them in equal batches)
+        const int slots = staged_slots(sc, n_runs);
+        const int n_batches = (n_runs + slots - 1) / slots, per_batch = (n_runs + n_batches - 1) / n_batches;
         char* base = ws + ws_off_staged(sc, n_runs);
         const size_t per_run = cap * (8 * (size_t)ncomp + 4 + 24 + 4);
         if (per_run + 16 > staged_slot_bytes(sc)) return fail(-5, "%s", "mosaic route: slot too small");
         KMosaic mo;
         memset(&mo, 0, sizeof(mo));
         char* p = base;
-        mo.cand = reinterpret_cast<double*>(p);  p += (size_t)n_runs * cap * 8 * (size_t)ncomp;
-        mo.draws = reinterpret_cast<double*>(p); p += (size_t)n_runs * cap * 24;
-        mo.list = reinterpret_cast<uint32_t*>(p); p += (size_t)n_runs * cap * 4;
-        mo.mark = reinterpret_cast<uint32_t*>(p); p += (size_t)n_runs * cap * 4;
+        mo.cand = reinterpret_cast<double*>(p);  p += (size_t)per_batch * cap * 8 * (size_t)ncomp;
+        mo.draws = reinterpret_cast<double*>(p); p += (size_t)per_batch * cap * 24;
+        mo.list = reinterpret_cast<uint32_t*>(p); p += (size_t)per_batch * cap * 4;
+        mo.mark = reinterpret_cast<uint32_t*>(p); p += (size_t)per_batch * cap * 4;
         // (the runs' counts: in the staged path's per-slot words behind the slots -- 16 bytes per slot)
-        uint32_t* d_flag = reinterpret_cast<uint32_t*>(base + (size_t)n_runs * (staged_slot_bytes(sc) - 16));
+        uint32_t* d_flag = reinterpret_cast<uint32_t*>(base + (size_t)per_batch * (staged_slot_bytes(sc) - 16));
         if ((char*)d_flag < p) return fail(-5, "%s", "mosaic route: slot layout");
         mo.n_cand = d_flag;
-        mo.gauss_state = reinterpret_cast<KState*>(ws + ws_off_gauss(sc, n_runs));
         mo.cap = (int64_t)cap; mo.be = be; mo.ncomp = ncomp;
         mo.dbg = reinterpret_cast<unsigned long long*>(ws + XRT_WS_STATUS_BYTE + 64);     // (development builds: the header's spare words)
-        HIP_TRY(hipMemsetAsync(d_flag, 0, sizeof(uint32_t) * (size_t)n_runs, stream));
-        a.streams = streams; a.heads = heads; a.n_runs = n_runs; a.n_src_heads = nh;
+        a.n_src_heads = nh;
         a.run_counter = reinterpret_cast<uint32_t*>(ws);
         a.progress = env_on("XICSRT_NO_PRIORITY_FEEDBACK") ? nullptr : reinterpret_cast<unsigned long long*>(ws + 32);
         // first phase: every run one unit (one segment, one part), the plain layout of the heads
@@ -4995,17 +4996,10 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
         a.unit_o = nullptr; a.split_interp = 0; a.dir_lds_bytes = 0;
         a.qcap = XRT_TILE; a.bragg_batch = 128u;
         const size_t lds3 = lds_bytes(nh, false, false, has_wl, XRT_TILE);
-        HIP_TRY(hipMemsetAsync(ws, 0, 64, stream));
-        int st = needs_full(sc) ? launch_variant<false, 1, 3>(device_scene(ws), a, n_runs, lds3, stream)
-                                : launch_variant<false, 0, 3>(device_scene(ws), a, n_runs, lds3, stream);
-        if (st) return st;
-        // the layers and the elements behind the crystal: a workgroup per run
-        KArgs am = a;
-        if (am.image_rep > 1u && am.images) am.images = am.images_rep;
         // (pixel bins in LDS for the reflected rays, where the scene's bins fit 40 KB of LDS together with the rest -- four
         //  workgroups per CU -- as 16-bit counters: they take the place of the ring, which is done by then, and what they need beyond)
         const uint32_t ring_words = XRT_PC_RING + XRT_PC_MIRROR + 4u, small_words = 2 * (XRT_DEV_MAX_OPTICS + 2) + 8 + XRT_PC_CTL + 4;
-        uint32_t bins_words = (am.images && sc->image_bins > 0 && sc->image_bins <= 19000 && !env_on("XICSRT_NO_LDS_BINS")) ? (uint32_t)((sc->image_bins + 1) / 2) : 0u;
+        const uint32_t bins_words = (a.images && sc->image_bins > 0 && sc->image_bins <= 19000 && !env_on("XICSRT_NO_LDS_BINS")) ? (uint32_t)((sc->image_bins + 1) / 2) : 0u;
         mo.lbins_words = bins_words;
         const size_t lds_mo = sizeof(uint32_t) * ((size_t)small_words + (bins_words > ring_words ? bins_words : ring_words));
         int ti = -1;
@@ -5015,9 +5009,22 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
             HIP_TRY(hipEventCreate(&timing_ev[ti][1]));
             HIP_TRY(hipEventRecord(timing_ev[ti][0], stream));
         }
-        HIP_TRY(hipMemsetAsync(ws, 0, 64, stream));
-        hipLaunchKernelGGL(xrt_mosaic_kernel, dim3((unsigned)(n_runs < 1024 ? n_runs : 1024)), dim3(XRT_TILE), lds_mo, stream, device_scene(ws), am, mo);
-        HIP_TRY(hipGetLastError());
+        for (int base_run = 0; base_run < n_runs; base_run += per_batch) {
+            const int nb = (n_runs - base_run) < per_batch ? (n_runs - base_run) : per_batch;
+            a.streams = streams + base_run; a.heads = heads + (size_t)base_run * (size_t)nh; a.n_runs = nb;
+            mo.gauss_state = reinterpret_cast<KState*>(ws + ws_off_gauss(sc, n_runs)) + base_run;
+            HIP_TRY(hipMemsetAsync(d_flag, 0, sizeof(uint32_t) * (size_t)nb, stream));
+            HIP_TRY(hipMemsetAsync(ws, 0, 64, stream));
+            const int st = needs_full(sc) ? launch_variant<false, 1, 3>(device_scene(ws), a, nb, lds3, stream)
+                                          : launch_variant<false, 0, 3>(device_scene(ws), a, nb, lds3, stream);
+            if (st) return st;
+            // the layers and the elements behind the crystal: a workgroup per run
+            KArgs am = a;
+            if (am.image_rep > 1u && am.images) am.images = am.images_rep;
+            HIP_TRY(hipMemsetAsync(ws, 0, 64, stream));
+            hipLaunchKernelGGL(xrt_mosaic_kernel, dim3((unsigned)(nb < 1024 ? nb : 1024)), dim3(XRT_TILE), lds_mo, stream, device_scene(ws), am, mo);
+            HIP_TRY(hipGetLastError());
+        }
         if (ti >= 0) HIP_TRY(hipEventRecord(timing_ev[ti][1], stream));
         return 0;
     }
