@@ -11,6 +11,7 @@ from xicsrt_amd import xicsrt_raytrace as xrt, capi
 import test_gpu_scale as scale
 
 HISTORY = '--history' in sys.argv
+MOSAIC_ROUTE_GIVEN = 'XICSRT_MOSAIC_FUSED_MIN' in os.environ       # (the caller's choice for every scene; else drawn per scene)
 if HISTORY:
     sys.argv.remove('--history')
 CRYSTAL_AT = [0.0, 0.0, 0.80374151]
@@ -109,7 +110,9 @@ def main():
             env['XICSRT_NO_JUMP'] = '1'
         if rs.rand() < 0.1:
             env['XICSRT_PLASMA_STAGED'] = '1'
-        for k in ('XICSRT_SEGMENTS', 'XICSRT_BRAGG_BATCH_128', 'XICSRT_NO_JUMP', 'XICSRT_PLASMA_STAGED'):
+        if rs.rand() < 0.5 and not MOSAIC_ROUTE_GIVEN:
+            env['XICSRT_MOSAIC_FUSED_MIN'] = '1'        # (mosaic crystals: these small scenes through xrt_mosaic_kernel too)
+        for k in ('XICSRT_SEGMENTS', 'XICSRT_BRAGG_BATCH_128', 'XICSRT_NO_JUMP', 'XICSRT_PLASMA_STAGED') + (() if MOSAIC_ROUTE_GIVEN else ('XICSRT_MOSAIC_FUSED_MIN',)):
             os.environ.pop(k, None)
         os.environ.update(env)
         dev = xrt.DeviceTrace(flat)
