@@ -2582,13 +2582,11 @@ void xrt_mesh_rest_kernel(const KScene* __restrict__ scene_g, const KArgs args, 
     const unsigned long long ab = __ballot(alive);
     if (args.slow_pass) {       // (the listed rays lie anywhere in the unit: they add to what the first launch counted)
         if (alive) atomicAdd(&args.batch_alive[((crun + (size_t)ray_lo) >> 6) + (kk >> 6)], 1u);
-        if (ab != 0ULL && (threadIdx.x & 63u) == 0u) atomicAdd(&args.unit_alive[unit], (uint32_t)__popcll(ab));
         return;
     }
     if ((threadIdx.x & 63u) == 0u) {
         const uint32_t n = (uint32_t)__popcll(ab);
         args.batch_alive[((crun + (size_t)ray_lo) >> 6) + 4u * blk + (threadIdx.x >> 6)] = n;
-        if (n) atomicAdd(&args.unit_alive[unit], n);
     }
 }
 
@@ -2677,13 +2675,11 @@ void xrt_mesh_rest_lds_kernel(const KScene* __restrict__ scene_g, const KArgs ar
         const unsigned long long ab = __ballot(alive);
         if (args.slow_pass) {       // (the listed rays lie anywhere in the unit: they add to what the first launch counted)
             if (alive) atomicAdd(&args.batch_alive[((crun + (size_t)ray_lo) >> 6) + (kk >> 6)], 1u);
-            if (ab != 0ULL && (tid & 63) == 0) atomicAdd(&args.unit_alive[unit], (uint32_t)__popcll(ab));
             continue;
         }
         if ((tid & 63) == 0 && 64u * (k >> 6) < ((n_unit + 63u) & ~63u)) {
             const uint32_t n = (uint32_t)__popcll(ab);
             args.batch_alive[((crun + (size_t)ray_lo) >> 6) + (k >> 6)] = n;
-            if (n) atomicAdd(&args.unit_alive[unit], n);
         }
     }
 }
@@ -2777,7 +2773,7 @@ __device__ __forceinline__ void mesh_star_blocks(const KScene* __restrict__ scen
         return F;
     };
     auto put = [&](const Block& B, const Found& F) __attribute__((always_inline)) {
-        const uint32_t unit = B.unit, k = B.k, n_unit = B.n_unit;
+        const uint32_t k = B.k, n_unit = B.n_unit;
         const size_t crun = B.crun;
         const int64_t ray_lo = B.ray_lo, i = ray_lo + (int64_t)k;
         if (F.settled) {
@@ -2797,7 +2793,6 @@ __device__ __forceinline__ void mesh_star_blocks(const KScene* __restrict__ scen
             if ((tid & 63) == 0 && in_unit) {
                 const uint32_t n = (uint32_t)__popcll(F.ab);
                 args.batch_alive[((crun + (size_t)ray_lo) >> 6) + (k >> 6)] = n;
-                if (n) atomicAdd(&args.unit_alive[unit], n);
             }
         }
     };
@@ -2905,6 +2900,38 @@ void xrt_mesh_items_kernel(const uint32_t* counts, uint32_t minus, uint32_t n_un
     if (tid == 0) *n_items = running;
 }
 
+// The parked rays a unit has left when the middle launches are through (what the second phase reads as the number of its Bragg
+// draws, KArgs.unit_alive): the sum of the unit's counts per 64 records.  A launch of its own, a workgroup per unit -- as an
+// atomic per wave of the middle launches it was 8e6 adds on a thousand addresses, 2.9 ms of the fan launch's 21.
+__global__ __launch_bounds__(256)
+void xrt_mesh_unit_alive_kernel(const KScene* __restrict__ scene_g, const KArgs args, uint32_t n_units)
+{
+    __shared__ uint32_t part[4];
+    const KScene* scl = scene_fresh(scene_g);
+    const uint32_t upr = (uint32_t)args.n_seg * (uint32_t)args.n_sub;
+    const int64_t N = SRC.n_rays;
+    for (uint32_t unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+        const uint32_t n_unit = uni32(args.unit_flag[unit]) - 1u;
+        const uint32_t run = unit / upr, uidx = unit - run * upr;
+        const uint32_t seg = uidx / (uint32_t)args.n_sub, sub = uidx - seg * (uint32_t)args.n_sub;
+        const int64_t seg_lo = (int64_t)seg * args.seg_len;
+        const int64_t seg_hi = (seg_lo + args.seg_len < N) ? seg_lo + args.seg_len : N;
+        int64_t ray_lo = seg_lo + (int64_t)sub * args.sub_len;
+        if (ray_lo > seg_hi) ray_lo = seg_hi;
+        const size_t crun = (size_t)run * (size_t)args.cand_cap;
+        const uint32_t* ba = args.batch_alive + ((crun + (size_t)ray_lo) >> 6);
+        const uint32_t groups = (n_unit + 63u) >> 6;
+        uint32_t sum = 0;
+        for (uint32_t g = threadIdx.x; g < groups; g += 256u) sum += ba[g];
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = sum;
+        __syncthreads();
+        if (threadIdx.x == 0) args.unit_alive[unit] = part[0] + part[1] + part[2] + part[3];
+        __syncthreads();
+    }
+}
+
+
 // The fan launch's lists (per 64 records of a unit) without their gaps: per unit one dense list for the launch that walks the
 // face lists, and its length.  A workgroup per unit, 256 runs of 64 records a step.
 __global__ __launch_bounds__(256)
@@ -2995,7 +3022,6 @@ void xrt_mesh_ct_kernel(const KScene* __restrict__ scene_g, const KArgs args, in
     if ((threadIdx.x & 63u) == 0u) {
         const uint32_t n = (uint32_t)__popcll(ab);
         args.batch_alive[((crun + (size_t)ray_lo) >> 6) + 4u * blk + (threadIdx.x >> 6)] = n;
-        if (n) atomicAdd(&args.unit_alive[unit], n);
     }
 }
 
@@ -3059,7 +3085,6 @@ void xrt_mesh_ct_lds_kernel(const KScene* __restrict__ scene_g, const KArgs args
         if ((tid & 63) == 0 && 64u * (k >> 6) < ((n_unit + 63u) & ~63u)) {
             const uint32_t n = (uint32_t)__popcll(ab);
             args.batch_alive[((crun + (size_t)ray_lo) >> 6) + (k >> 6)] = n;
-            if (n) atomicAdd(&args.unit_alive[unit], n);
         }
     }
 }
@@ -5419,6 +5444,9 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
                 } else
                     hipLaunchKernelGGL(xrt_mesh_ct_kernel, dim3((unsigned)blocks), dim3(XRT_TILE), 0, stream, device_scene(ws), am, be, bpu);
             }
+            HIP_TRY(hipGetLastError());
+            // the rays every unit has left: the sums of its counts per 64 records
+            hipLaunchKernelGGL(xrt_mesh_unit_alive_kernel, dim3(n_units < 2048u ? n_units : 2048u), dim3(256), 0, stream, device_scene(ws), am, n_units);
             HIP_TRY(hipGetLastError());
             if (ti >= 0) HIP_TRY(hipEventRecord(timing_ev[ti][1], stream));
             HIP_TRY(hipMemsetAsync(ws, 0, 64, stream));
