@@ -1192,6 +1192,9 @@ struct KArgs {
     // (split_interp != 0): the hit point in place of the origin (its height from the interpolation) and the interpolated
     // normal in components 6 - 8 (between the two middle launches component 6 holds the nearest point).
     uint32_t  split_interp;
+    // ... and a mesh that is not interpolated straight behind a point source (unit_o below): the records hold nothing but the
+    // direction [and the wavelength] -- components 0 - 2 [3], 24 - 32 B instead of 48 - 56
+    uint32_t  split_lean;
     // A mesh crystal straight behind a point source: every parked ray of the call has the same (local-frame) origin.  The first
     // phase then leaves it ONCE per unit (unit_o[unit][3], from the unit's first parked ray -- the device's own arithmetic) and
     // not in the records (24 of their 52 bytes); the middle launches and the second phase take it from there.  Null: per ray.
@@ -1390,7 +1393,9 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
     size_t crun = 0;                // first ray-index / face word of the run
     // (blocks of 256 records, component-major inside a block: what a batch reads lies in one 12 - 14 KB stretch)
     // (split phases: + the surface normal at the hit point, components 6 - 8, which xrt_mesh_rest_kernel leaves)
-    const int q_wlc = (SPLIT && args.split_interp) ? 9 : 6;
+    const bool q_lean = SPLIT && args.split_lean != 0u;           // (records without the origin: KArgs.split_lean)
+    const int q_d0 = q_lean ? 0 : 3;                               // first component of the direction
+    const int q_wlc = q_lean ? 3 : ((SPLIT && args.split_interp) ? 9 : 6);
     const int q_ncomp = q_wlc + (q_has_wl ? 1 : 0);
     auto cand_store = [&](int64_t i, const V3& o, const V3& d, double wl, uint32_t id, int aux) __attribute__((always_inline)) {
         if constexpr (SEG == 3 && !EXT) {
@@ -1404,7 +1409,7 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
         bool shared_o = false;
         if constexpr (SPLIT) shared_o = args.unit_o != nullptr;
         if (!shared_o) { c[0 * 256] = o.x; c[1 * 256] = o.y; c[2 * 256] = o.z; }
-        c[3 * 256] = d.x; c[4 * 256] = d.y; c[5 * 256] = d.z;
+        c[q_d0 * 256] = d.x; c[(q_d0 + 1) * 256] = d.y; c[(q_d0 + 2) * 256] = d.z;
         if (q_has_wl) c[q_wlc * 256] = wl;
         if (HIST) args.cand_id[crun + i] = id;
         if (EXT) args.cand_aux[crun + i] = (uint32_t)aux;
@@ -1415,7 +1420,7 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
         bool skip_o = false;
         if constexpr (SPLIT) skip_o = args.unit_o != nullptr && !args.split_interp;
         if (!skip_o) { o.x = c[0 * 256]; o.y = c[1 * 256]; o.z = c[2 * 256]; }
-        d.x = c[3 * 256]; d.y = c[4 * 256]; d.z = c[5 * 256];
+        d.x = c[q_d0 * 256]; d.y = c[(q_d0 + 1) * 256]; d.z = c[(q_d0 + 2) * 256];
         wl = q_has_wl ? c[q_wlc * 256] : wl_run;
         id = HIST ? args.cand_id[crun + i] : 0u;
         aux = EXT ? (int)args.cand_aux[crun + i] : 0;
@@ -2163,13 +2168,15 @@ void xrt_trace_kernel(const KScene* __restrict__ scene_g, const KArgs args)
                     const int wave = tid >> 6, lane = tid & 63;
                     // the workgroup's LDS in front of `small`, re-carved: four rings, four survivor queues
                     uint32_t* wring = reinterpret_cast<uint32_t*>(lds_raw) + wave * XRT_RING;
-                    const uint32_t rec_bytes = 8u * (uint32_t)q_ncomp + (HIST ? 4u : 0u);
+                    // (a queued ray: point, direction[, wavelength] -- whatever the parked records hold, see KArgs.split_lean)
+                    const uint32_t wq_comps = q_has_wl ? 7u : 6u;
+                    const uint32_t rec_bytes = 8u * wq_comps + (HIST ? 4u : 0u);
                     const uint32_t pool = ((uint32_t)(reinterpret_cast<unsigned char*>(small) - lds_raw) - 4u * 4u * XRT_RING) / 4u & ~7u;
                     uint32_t wq_cap = pool / rec_bytes;
                     if (wq_cap > 128u) wq_cap = 128u;
                     wq_cap &= ~1u;
-                    double* wq = reinterpret_cast<double*>(lds_raw + 4u * 4u * XRT_RING + (size_t)wave * pool);       // [q_ncomp][wq_cap]
-                    uint32_t* wqid = reinterpret_cast<uint32_t*>(wq + (size_t)q_ncomp * wq_cap);                         // [wq_cap] (HIST)
+                    double* wq = reinterpret_cast<double*>(lds_raw + 4u * 4u * XRT_RING + (size_t)wave * pool);       // [wq_comps][wq_cap]
+                    uint32_t* wqid = reinterpret_cast<uint32_t*>(wq + (size_t)wq_comps * wq_cap);                        // [wq_cap] (HIST)
                     // batches of 64 candidates [kb, ke) of this wave: 26 / 25.5 / 24.5 / 24 % of them
                     const uint32_t n_batches = (n_candidates + 63u) >> 6;
                     const uint32_t cut[5] = {0u, (n_batches * 133u + 256u) >> 9, (n_batches * 264u + 256u) >> 9, (n_batches * 389u + 256u) >> 9, n_batches};
@@ -2548,7 +2555,8 @@ void xrt_mesh_rest_kernel(const KScene* __restrict__ scene_g, const KArgs args, 
     int64_t ray_lo = seg_lo + (int64_t)sub * args.sub_len;
     if (ray_lo > seg_hi) ray_lo = seg_hi;
     const bool q_has_wl = !(SRC.wavelength_dist == XRT_WL_CONST && !SRC.has_velocity);
-    const int q_ncomp = (args.split_interp ? 9 : 6) + (q_has_wl ? 1 : 0);
+    const int q_d0 = args.split_lean ? 0 : 3;                    // (records without the origin: KArgs.split_lean)
+    const int q_ncomp = (args.split_lean ? 3 : (args.split_interp ? 9 : 6)) + (q_has_wl ? 1 : 0);
     const size_t crun = (size_t)run * (size_t)args.cand_cap;
     const bool have = 256u * blk + (uint32_t)threadIdx.x < n_unit;
     uint32_t kk = 256u * blk + (uint32_t)threadIdx.x;          // the record's number within its unit
@@ -2563,7 +2571,7 @@ void xrt_mesh_rest_kernel(const KScene* __restrict__ scene_g, const KArgs args, 
         // (the origin: the ray's own, or the one every parked ray of the unit has -- KArgs.unit_o)
         const double* po = args.unit_o ? args.unit_o + 3 * (size_t)unit : nullptr;
         const double ox = po ? po[0] : c[0 * 256], oy = po ? po[1] : c[1 * 256], oz = po ? po[2] : c[2 * 256];
-        const MeshHit h = mesh_rest_impl<false>(op.mesh, ox, oy, oz, c[3 * 256], c[4 * 256], c[5 * 256], face, &idx);
+        const MeshHit h = mesh_rest_impl<false>(op.mesh, ox, oy, oz, c[q_d0 * 256], c[(q_d0 + 1) * 256], c[(q_d0 + 2) * 256], face, &idx);
         V3 X;
         X.x = h.x; X.y = h.y; X.z = h.z;
         // (what is left of the ray: the face it ended on, or XRT_CAND_DEAD -- see KArgs.split_interp)
@@ -2629,7 +2637,8 @@ void xrt_mesh_rest_lds_kernel(const KScene* __restrict__ scene_g, const KArgs ar
     L.first = (const XRT_LDS3 double*)l_first;
     const int64_t N = SRC.n_rays;
     const bool q_has_wl = !(SRC.wavelength_dist == XRT_WL_CONST && !SRC.has_velocity);
-    const int q_ncomp = (args.split_interp ? 9 : 6) + (q_has_wl ? 1 : 0);
+    const int q_d0 = args.split_lean ? 0 : 3;                    // (records without the origin: KArgs.split_lean)
+    const int q_ncomp = (args.split_lean ? 3 : (args.split_interp ? 9 : 6)) + (q_has_wl ? 1 : 0);
     const uint32_t upr = (uint32_t)args.n_seg * (uint32_t)args.n_sub;
     // (unit, block of 1024 rays) from the list of the blocks that hold rays; slow_pass: the rays xrt_mesh_star_lds_kernel listed
     const uint32_t n_it = uni32(*args.n_items);
@@ -2657,7 +2666,7 @@ void xrt_mesh_rest_lds_kernel(const KScene* __restrict__ scene_g, const KArgs ar
             nrm.x = nrm.y = nrm.z = 0.0;
             const double* po = args.unit_o ? args.unit_o + 3 * (size_t)unit : nullptr;
             const double ox = po ? po[0] : c[0 * 256], oy = po ? po[1] : c[1 * 256], oz = po ? po[2] : c[2 * 256];
-            const MeshHit h = mesh_rest_lds(Mp, L, ox, oy, oz, c[3 * 256], c[4 * 256], c[5 * 256], face, idx, nrm);
+            const MeshHit h = mesh_rest_lds(Mp, L, ox, oy, oz, c[q_d0 * 256], c[(q_d0 + 1) * 256], c[(q_d0 + 2) * 256], face, idx, nrm);
             V3 X;
             X.x = h.x; X.y = h.y; X.z = h.z;
             if constexpr (DEFER) {
@@ -2697,7 +2706,8 @@ __device__ __forceinline__ void mesh_star_blocks(const KScene* __restrict__ scen
     const int tid = threadIdx.x;
     const int64_t N = SRC.n_rays;
     const bool q_has_wl = !(SRC.wavelength_dist == XRT_WL_CONST && !SRC.has_velocity);
-    const int q_ncomp = (args.split_interp ? 9 : 6) + (q_has_wl ? 1 : 0);
+    const int q_d0 = args.split_lean ? 0 : 3;                    // (records without the origin: KArgs.split_lean)
+    const int q_ncomp = (args.split_lean ? 3 : (args.split_interp ? 9 : 6)) + (q_has_wl ? 1 : 0);
     const uint32_t upr = (uint32_t)args.n_seg * (uint32_t)args.n_sub;
     // One block (1024 records, 64 per wave) per round, in this order: (1) the item of the NEXT block -- asked for a round ago --
     // is taken up, (2) what the round BEFORE found is stored, (3) the next block's records and the item of the block after
@@ -2738,7 +2748,7 @@ __device__ __forceinline__ void mesh_star_blocks(const KScene* __restrict__ scen
         R.face = 0;
         if (B.have) {
 #pragma unroll
-            for (int q = 0; q < 6; q++) if (q >= q0) R.r[q] = B.c[q * 256];
+            for (int q = 0; q < 6; q++) if (q >= q0) R.r[q] = B.c[(q < 3 ? q : q - 3 + q_d0) * 256];
             R.face = (int)args.cand_aux[B.crun + (size_t)(B.ray_lo + (int64_t)B.k)];
             if (args.unit_o) { const double* uo = args.unit_o + 3 * (size_t)B.unit; R.r[0] = uo[0]; R.r[1] = uo[1]; R.r[2] = uo[2]; }
         }
@@ -2995,7 +3005,7 @@ void xrt_mesh_ct_kernel(const KScene* __restrict__ scene_g, const KArgs args, in
     int64_t ray_lo = seg_lo + (int64_t)sub * args.sub_len;
     if (ray_lo > seg_hi) ray_lo = seg_hi;
     const bool q_has_wl = !(SRC.wavelength_dist == XRT_WL_CONST && !SRC.has_velocity);
-    const int q_ncomp = (args.split_interp ? 9 : 6) + (q_has_wl ? 1 : 0);
+    const int q_ncomp = (args.split_lean ? 3 : (args.split_interp ? 9 : 6)) + (q_has_wl ? 1 : 0);
     const size_t crun = (size_t)run * (size_t)args.cand_cap;
     const int64_t i = ray_lo + (int64_t)(256u * blk + (uint32_t)threadIdx.x);
     double* c = args.cand + crun * (size_t)q_ncomp + (i >> 8) * (int64_t)(q_ncomp * 256) + (i & 255);
@@ -3047,7 +3057,7 @@ void xrt_mesh_ct_lds_kernel(const KScene* __restrict__ scene_g, const KArgs args
     const XRT_LDS3 double* lv = (const XRT_LDS3 double*)l_v;
     const int64_t N = SRC.n_rays;
     const bool q_has_wl = !(SRC.wavelength_dist == XRT_WL_CONST && !SRC.has_velocity);
-    const int q_ncomp = (args.split_interp ? 9 : 6) + (q_has_wl ? 1 : 0);
+    const int q_ncomp = (args.split_lean ? 3 : (args.split_interp ? 9 : 6)) + (q_has_wl ? 1 : 0);
     const uint32_t upr = (uint32_t)args.n_seg * (uint32_t)args.n_sub;
     const uint32_t n_it = uni32(*args.n_items);
     for (uint32_t ii = blockIdx.x; ii < n_it; ii += gridDim.x) {
@@ -3587,12 +3597,20 @@ static size_t seg_bytes(const xrt_scene_t* sc, int n_runs)
 static size_t cand_capacity(const xrt_scene_t* sc) { return ((size_t)(sc->source.intensity > 0 ? sc->source.intensity : 1) + 255) & ~(size_t)255; }
 // doubles of a parked ray's record between the launches of a split trace (KArgs.split_interp): origin, direction
 // [, interpolated normal] [, wavelength]
+// (the mesh straight behind a source without extent: one origin for every parked ray of a unit, KArgs.unit_o)
+static bool split_shared_origin(const xrt_scene_t* sc)
+{
+    const xrt_source_t& src = sc->source;
+    return bragg_element(sc) == 0 && (src.kind == XRT_SRC_GENERIC || src.kind == XRT_SRC_DIRECTED) && src.spatial_dist == XRT_SPATIAL_UNIFORM &&
+           src.size[0] == 0.0 && src.size[1] == 0.0 && src.size[2] == 0.0 && !env_on("XICSRT_NO_SHARED_ORIGIN");
+}
 static int split_comps(const xrt_scene_t* sc)
 {
     const int be = bragg_element(sc);
     const bool interp = be >= 0 && sc->optics[be].mesh && sc->optics[be].mesh->interpolate;
     const bool has_wl = !(sc->source.wavelength_dist == XRT_WL_CONST && !sc->source.has_velocity);
-    return (interp ? 9 : 6) + (has_wl ? 1 : 0);
+    const bool lean = !interp && split_shared_origin(sc);       // (KArgs.split_lean: the records hold no origin)
+    return (lean ? 3 : (interp ? 9 : 6)) + (has_wl ? 1 : 0);
 }
 static size_t mesh_split_off_aux(const xrt_scene_t* sc, int n_runs) { return al256((size_t)n_runs * cand_capacity(sc) * 8 * (size_t)split_comps(sc)); }
 static size_t mesh_split_off_batch_alive(const xrt_scene_t* sc, int n_runs) { return mesh_split_off_aux(sc, n_runs) + al256((size_t)n_runs * cand_capacity(sc) * 4); }
@@ -5297,10 +5315,9 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
             a.slow_pass = 0;
             a.split_interp = (sc->optics[be].mesh && sc->optics[be].mesh->interpolate) ? 1u : 0u;
             {   // the mesh straight behind a source without extent: one origin for every parked ray (KArgs.unit_o)
-                const xrt_source_t& src = sc->source;
-                const bool point = be == 0 && (src.kind == XRT_SRC_GENERIC || src.kind == XRT_SRC_DIRECTED) && src.spatial_dist == XRT_SPATIAL_UNIFORM &&
-                                   src.size[0] == 0.0 && src.size[1] == 0.0 && src.size[2] == 0.0 && !env_on("XICSRT_NO_SHARED_ORIGIN");
+                const bool point = split_shared_origin(sc);
                 a.unit_o = point ? reinterpret_cast<double*>(cb + mesh_split_off_unit_o(sc, n_runs, plan)) : nullptr;
+                a.split_lean = (point && !a.split_interp) ? 1u : 0u;
             }
             a.cand_cap = (int64_t)cand_capacity(sc);
             a.unit_flag = d_cnt;
