@@ -218,6 +218,9 @@ def test_workspace_of_a_mesh_crystal_holds_the_parked_rays_within_the_budget(mon
     assert full < (48 << 30)
     assert L.xrt_workspace_bytes(flat.byref(), 2000) == full          # two batches of 1000
     assert full < L.xrt_workspace_bytes(flat.byref(), 4000) < (48 << 30)       # three batches of 1334
+    # a single run's workspace also serves xrt_trace_history, which takes the one-pass route WITHOUT the split: 64 B per ray of
+    # capacity there (found by a fuzz sweep: with the records without origin the split's region had become the smaller one)
+    assert L.xrt_workspace_bytes(flat.byref(), 1) > cap * 64
     few = L.xrt_workspace_bytes(flat.byref(), 300)
     assert 300 * per_run < few < 300 * per_run + (4 << 30)           # fits as it is
     # a tighter budget: smaller batches

@@ -3648,7 +3648,12 @@ static size_t cand_bytes(const xrt_scene_t* sc, int n_runs, size_t budget)
         // split phases: 10 doubles (+ the normal) and the face per ray, the rays left alive per 64 and per unit.  (A call whose
         // runs would take more than the budget goes through them in batches, mesh_batch_runs; what is left over the budget
         // here is a single run of > 6e8 rays.)
-        const size_t b = mesh_split_end(sc, n_runs, p) + 256;
+        // A history call of the same scene (xrt_trace_history: one run) takes the one-pass route WITHOUT the split (64 B per ray
+        // of capacity: 7 doubles, ray index, face) over the same workspace: a single run's region holds whichever is larger --
+        // records without the origin (KArgs.split_lean) make the split's the smaller one.
+        size_t b = mesh_split_end(sc, n_runs, p) + 256;
+        const size_t plain = al256((size_t)n_runs * cand_capacity(sc) * 64) + 256;
+        if (n_runs == 1 && p.n_seg * p.n_sub > 1 && plain > b) b = plain;
         return b <= budget ? b : 0;
     }
     if (p.n_seg * p.n_sub <= 1) return 0;
@@ -5326,6 +5331,9 @@ static int run_iteration(const xrt_scene_t* sc, const KScene& ks, char* ws, size
             HIP_TRY(hipMemsetAsync(a.unit_slow, 0, sizeof(uint32_t) * (size_t)n_runs * (size_t)S * (size_t)M, stream));
             g_paths |= XRT_PATH_ONE_PASS | XRT_PATH_MESH_SPLIT;
         } else
+        if (one_pass && ws_base_bytes(sc, n_runs) + al256((size_t)n_runs * cand_capacity(sc) * 64) + 256 > ws_bytes)
+            return fail(-4, "%s", "workspace too small for the parked candidates of the one-pass route");
+        else
         if (one_pass) {
             const size_t cap = cand_capacity(sc);
             char* cb = ws + ws_base_bytes(sc, n_runs);
