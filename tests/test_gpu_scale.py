@@ -228,11 +228,13 @@ def test_mesh_crystal_routes_equal_reference(name, route, monkeypatch):
     if route == 'split_batches':                                    # a budget that holds one of the two runs: batches of runs
         cap = (flat.n_rays + 255) // 256 * 256
         whole = capi.lib().xrt_workspace_bytes(flat.byref(), 2)
-        for mb in range(int(2 * cap * 100) // (1 << 20) + 2, 0, -1):       # (56 - 96 bytes per parked ray, by the mesh and the source)
+        # (36 - 96 bytes per parked ray, by the mesh and the source; a single run's region holds 64 B per ray at least: what a
+        #  history call of the scene parks)
+        for mb in range(int(2 * cap * 100) // (1 << 20) + 2, 0, -1):
             monkeypatch.setenv('XICSRT_WORKSPACE_BUDGET_MB', str(mb))
-            if capi.lib().xrt_workspace_bytes(flat.byref(), 2) < whole - cap * 40:
+            if capi.lib().xrt_workspace_bytes(flat.byref(), 2) < whole - cap * 4:
                 break
-        assert capi.lib().xrt_workspace_bytes(flat.byref(), 2) < whole - cap * 40
+        assert capi.lib().xrt_workspace_bytes(flat.byref(), 2) < whole - cap * 4
     g = config['general']
     seeds = xrt.run_seeds(g['random_seed'], g['number_of_runs'])
     capi.lib().xrt_last_path(1)

@@ -3652,9 +3652,10 @@ static size_t cand_bytes(const xrt_scene_t* sc, int n_runs, size_t budget)
         // of capacity: 7 doubles, ray index, face) over the same workspace: a single run's region holds whichever is larger --
         // records without the origin (KArgs.split_lean) make the split's the smaller one.
         size_t b = mesh_split_end(sc, n_runs, p) + 256;
+        if (b > budget) return 0;                       // (the budget is the split route's: what the history call needs on top is one run's)
         const size_t plain = al256((size_t)n_runs * cand_capacity(sc) * 64) + 256;
         if (n_runs == 1 && p.n_seg * p.n_sub > 1 && plain > b) b = plain;
-        return b <= budget ? b : 0;
+        return b;
     }
     if (p.n_seg * p.n_sub <= 1) return 0;
     const size_t b = al256((size_t)n_runs * cand_capacity(sc) * 64) + 256;
