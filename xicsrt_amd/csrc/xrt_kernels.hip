@@ -4721,7 +4721,11 @@ static int upload_meshes(const xrt_scene_t* sc, char* ws, int n_runs, KScene* ks
                 //  moment ago: they are released only after that device's work has drained -- rare, and off the common path)
                 size_t old = 0;
                 for (size_t i = 1; i < g_mesh_cache.size(); i++) if (g_mesh_cache[i].used < g_mesh_cache[old].used) old = i;
-                (void)hipDeviceSynchronize();
+                if (g_mesh_cache[old].dev != dev_now) {       // (the entry of another device -- another host thread's: its work, not ours)
+                    (void)hipSetDevice(g_mesh_cache[old].dev);
+                    (void)hipDeviceSynchronize();
+                    (void)hipSetDevice(dev_now);
+                } else (void)hipDeviceSynchronize();
                 (void)hipHostFree(g_mesh_cache[old].pinned);
                 g_mesh_cache[old] = c;
             } else g_mesh_cache.push_back(c);
